@@ -1,0 +1,157 @@
+"""Pin the CPU oracle to golden vectors produced by the reference's own modules
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import simclr_oracle as O
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _u8(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+
+
+@pytest.mark.parametrize("tag", ["b8", "b16", "b64", "b33"])
+def test_ntxent_single(golden_dir, tag):
+    G = _load(golden_dir, "ntxent_single.npz")
+    b, d, tau, seed = G[f"{tag}_cfg"]
+    b, d, seed = int(b), int(d), int(seed)
+    torch.manual_seed(seed)
+    h1, h2 = torch.randn(b, d), torch.randn(b, d)
+    loss, logits, labels = O.nt_xent(h1, h2, float(tau))
+    np.testing.assert_allclose(loss.item(), G[f"{tag}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(logits.numpy(), G[f"{tag}_logits"], rtol=1e-5, atol=1e-6)
+    assert (labels.argmax(1).numpy() == G[f"{tag}_labels_argmax"]).all()
+    assert labels.shape == (b, 2 * b) and labels.dtype == torch.int64
+    _, g = O.nt_xent_grad_h2(h1, h2, float(tau))
+    np.testing.assert_allclose(g.numpy(), G[f"{tag}_dh2"], rtol=1e-4, atol=1e-7)
+    l3, _, _ = O.nt_xent(h1 * 0.1, h2 * 0.1, float(tau), hidden_norm=False)
+    np.testing.assert_allclose(l3.item(), G[f"{tag}_loss_nonorm"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ntxent_multirank_semantics(golden_dir, world):
+    G = _load(golden_dir, "ntxent_gloo.npz")
+    torch.manual_seed(1234)
+    H1, H2 = torch.randn(world * 8, 128), torch.randn(world * 8, 128)
+    Z1, Z2 = O.l2_normalize(H1), O.l2_normalize(H2)
+    losses = []
+    for r in range(world):
+        h1, h2 = H1[r * 8:(r + 1) * 8], H2[r * 8:(r + 1) * 8]
+        loss, g = O.nt_xent_grad_h2(h1, h2, 0.5, True, r, world, (Z1, Z2))
+        _, logits, labels = O.nt_xent(h1, h2, 0.5, True, r, world, (Z1, Z2))
+        losses.append(loss.item())
+        np.testing.assert_allclose(loss.item(), G[f"w{world}_loss"][r], rtol=1e-6)
+        np.testing.assert_allclose(logits.numpy(), G[f"w{world}_logits"][r], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(g.numpy(), G[f"w{world}_dh2"][r], rtol=1e-4, atol=1e-7)
+        assert (labels.argmax(1).numpy() == G[f"w{world}_labels_argmax"][r]).all()
+    np.testing.assert_allclose(np.mean(losses), G[f"w{world}_global_loss"], rtol=1e-6)
+
+
+def test_resnet18_cfg1_step(golden_dir):
+    G = _load(golden_dir, "r18_cfg1.npz")
+    B = 16
+    x1 = _u8(100, (B, 3, 32, 32)).float()
+    x2 = _u8(101, (B, 3, 32, 32)).float()
+    sd = O.pattern_state_dict("resnet18", 1, 512 * 16)
+    opt = {}
+    traj = []
+    h1 = None
+    for step in range(3):
+        r = O.train_step(sd, opt, x1, x2, "resnet18", 0.5, 1e-3, h1_prev=h1)
+        traj.append(r["loss"].item())
+        if step == 0:
+            np.testing.assert_allclose(r["z1"].numpy(), G["z1"], rtol=1e-3, atol=1e-4)
+            np.testing.assert_allclose(r["z2"].numpy(), G["z2"], rtol=1e-3, atol=1e-4)
+            np.testing.assert_allclose(r["loss"].item(), G["loss"], rtol=1e-5)
+            np.testing.assert_allclose(r["logits"].numpy(), G["logits"], rtol=1e-3, atol=1e-4)
+            g = r["grads"]
+            for key, name in [("g_conv1", "f.conv1.weight"), ("g_bn1_w", "f.bn1.weight"), ("g_bn1_b", "f.bn1.bias"),
+                              ("g_l2_ds", "f.layer2.0.downsample.0.weight"), ("g_fc2_w", "g.layers.2.weight"),
+                              ("g_fc2_b", "g.layers.2.bias"), ("g_fc1_b", "g.layers.0.bias")]:
+                ref = G[key]
+                err = np.abs(g[name].numpy() - ref).max() / (np.abs(ref).max() + 1e-30)
+                assert err < 1e-2, (key, err)
+            ref = G["g_l4_conv2"]
+            got = g["f.layer4.1.conv2.weight"][:16, :16].numpy()
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-2
+            gn = np.array([g[k].norm().item() for k in O.trainable_keys(sd)])
+            np.testing.assert_allclose(gn, G["gnorms"], rtol=1e-2)
+            np.testing.assert_allclose(sd["f.bn1.running_mean"].numpy(), G["bn1_rm"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(sd["f.bn1.running_var"].numpy(), G["bn1_rv"], rtol=1e-4)
+            np.testing.assert_allclose(sd["f.layer4.1.bn2.running_mean"].numpy(), G["l4_bn2_rm"], rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(sd["f.layer4.1.bn2.running_var"].numpy(), G["l4_bn2_rv"], rtol=1e-3)
+            # two train-mode forwards happened (view 1 + view 2): torch counts both
+            assert int(sd["f.bn1.num_batches_tracked"]) == int(G["nbt"])
+        h1 = r["z2"]
+    np.testing.assert_allclose(traj, G["traj"], rtol=2e-3)
+    # Adam moves every weight by ~lr per step whatever the gradient size, so fp32 noise in tiny
+    # gradients shows up at a fraction of 3*lr; 1e-3 = one step.
+    np.testing.assert_allclose(sd["f.conv1.weight"][:4].numpy(), G["conv1_after"], atol=1e-3)
+
+
+def test_resnet50_native_views(golden_dir):
+    G = _load(golden_dir, "r50_native.npz")
+    B = 8
+    views = [_u8(200 + k, (B, 30, 30, 3)) for k in range(4)]
+    sd = O.pattern_state_dict("resnet50", 4, 2048 * 16)
+    x = O.pack_views(views, B, (30, 30))
+    ns = {}
+    z = O.simclr_forward(sd, x, "resnet50", True, "fp32", ns)
+    np.testing.assert_allclose(z.numpy(), G["z"], rtol=5e-4, atol=5e-5)
+    np.testing.assert_allclose(ns["f.layer1.0.bn3.running_mean"].numpy(), G["l1_bn3_rm"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ns["f.layer1.0.bn3.running_var"].numpy(), G["l1_bn3_rv"], rtol=1e-4)
+    sd.update(ns)
+    z_eval = O.simclr_forward(sd, x, "resnet50", False)
+    np.testing.assert_allclose(z_eval.numpy(), G["z_eval"], rtol=5e-4, atol=5e-5)
+
+
+def test_resnet50_pool_head(golden_dir):
+    G = _load(golden_dir, "r50_pool.npz")
+    x = _u8(300, (4, 3, 64, 64)).float()
+    sd = O.pattern_state_dict("resnet50", 1, 2048 * 16)
+    feat = O.backbone_forward(sd, x, "resnet50", True)
+    np.testing.assert_allclose(feat.mean(dim=(2, 3)).numpy(), G["feat_mean"], rtol=5e-4, atol=5e-5)
+    z = O.head_forward(sd, feat, pool=4)
+    np.testing.assert_allclose(z.numpy(), G["z"], rtol=5e-4, atol=5e-5)
+
+
+def test_bf16_storage_mode_close_to_fp32():
+    """Document how far the bf16-storage emulation sits from fp32 (the tolerance
+    the end-to-end GPU parity test inherits)."""
+    x = _u8(100, (16, 3, 32, 32)).float()
+    sd = O.pattern_state_dict("resnet18", 1, 512 * 16)
+    z32 = O.simclr_forward(sd, x, "resnet18", True, "fp32")
+    z16 = O.simclr_forward(sd, x, "resnet18", True, "bf16")
+    cos = torch.nn.functional.cosine_similarity(z32, z16, dim=1)
+    assert cos.min() > 0.999
+    assert (z32 - z16).abs().max() / z32.abs().max() < 0.05
+
+
+def test_host_utils(golden_dir):
+    G = _load(golden_dir, "host_utils.npz")
+    for row in G["lr_rows"]:
+        step, warm, nex, bs, W, ep, scal, base, lr = row
+        got = O.lr_at_step(int(step), base, warm, int(nex), int(bs), int(W), int(ep), "linear" if scal == 0 else "sqrt")
+        np.testing.assert_allclose(got, lr, rtol=1e-12)
+    np.testing.assert_allclose(O.lr_at_step(1, 0.01, 10, 1000, 64, 8, 190), 1.2820512820512820e-4, rtol=1e-12)
+    torch.manual_seed(7)
+    preds = torch.randn(32, 20)
+    tgt = torch.randint(0, 20, (32,))
+    onehot = torch.nn.functional.one_hot(tgt, 40)
+    got = [O.top_k_accuracy(preds, tgt, k).item() for k in (1, 5)] + [O.top_k_accuracy(preds, onehot, k).item() for k in (1, 5)]
+    np.testing.assert_allclose(got, G["topk"])
+    known = [O.top_k_accuracy(torch.tensor([[.1, .9, 0], [.8, .1, .1]]), torch.tensor([1, 2]), k).item() for k in (1, 2)]
+    np.testing.assert_allclose(known, G["topk_known"])
+    torch.manual_seed(0)
+    z1, z2 = torch.randn(8, 128), torch.randn(8, 128)
+    np.testing.assert_allclose(O.legacy_compute_loss(z1, z2, 0.5).item(), G["legacy_loss"], rtol=1e-5)
+    with pytest.raises(ValueError):
+        O.lr_at_step(1, 0.01, 10, 1000, 64, 8, 190, "cubic")
