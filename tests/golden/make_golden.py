@@ -39,11 +39,11 @@ def inputs_uniform_u8(seed, shape):
     return torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
 
 
-def build_ref(arch, cm, head_in, batch, img):
+def build_ref(arch, cm, head_in, batch, img, rg=1.0):
     f = getattr(rn, arch)(crop_measures=cm)
     g = mlp.MLP(head_in, 1024, 128)
     m = SimCLR.SimCLR_Module(f, g, batch, img, "cpu")
-    m.load_state_dict(O.pattern_state_dict(arch, cm, head_in), strict=True)
+    m.load_state_dict(O.pattern_state_dict(arch, cm, head_in, residual_gamma=rg), strict=True)
     return m
 
 
@@ -145,7 +145,7 @@ if __name__ == "__main__":
     # ---- 4. ResNet-50 native geometry via SimCLR_Module.forward: 4 u8 HWC views, 12x30x30, B=8 ----
     B = 8
     views = [inputs_uniform_u8(200 + k, (B, 30, 30, 3)) for k in range(4)]
-    m = build_ref("resnet50", 4, 2048 * 16, B, (30, 30)); m.train()
+    m = build_ref("resnet50", 4, 2048 * 16, B, (30, 30), 0.25); m.train()
     z = m(views)
     sd = m.state_dict()
     m.eval()
@@ -156,7 +156,7 @@ if __name__ == "__main__":
     # ---- 4b. ResNet-50 at 3x64x64 with the 4x4 adaptive pool head (the cfg2 topology, small) ----
     B = 4
     x = inputs_uniform_u8(300, (B, 3, 64, 64)).float()
-    m = build_ref("resnet50", 1, 2048 * 16, B, (64, 64)); m.train()
+    m = build_ref("resnet50", 1, 2048 * 16, B, (64, 64), 0.25); m.train()
     feat = m.f(x)
     z = m.g(torch.nn.functional.adaptive_avg_pool2d(feat, (4, 4)))
     save("r50_pool.npz", z=z, feat_mean=feat.mean(dim=(2, 3)))
