@@ -1,0 +1,181 @@
+/*
+ * maai_hip.h — C ABI of the MI355X-native (gfx950 / CDNA4) SimCLR hot path.
+ *
+ * The reference (dariodematties/Multimodal-Active-AI) is pure Python on
+ * torch; it has no FFI of its own.  Its hot path reaches the device through
+ * torch operators, so each entry point below names the reference call site
+ * (file:line under /root/reference) whose device work it replaces.  The
+ * Python mirror of the reference interface (multimodal-active-ai_amd/SimCLR/…)
+ * binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host;
+ *   - activations are NHWC; dtype is MAAI_BF16 (bf16 storage, fp32 MFMA
+ *     accumulate) or MAAI_F32 (fp32 storage, exact fp32 MFMA — parity mode);
+ *   - `stream` is a hipStream_t passed as void*; nothing here synchronises,
+ *     allocates or frees (graph-capturable); workspaces come from the caller;
+ *   - return 0 on success, non-zero otherwise (maai_last_error() has the text);
+ *     no C++ exception crosses this boundary;
+ *   - thread-safe with respect to distinct streams.
+ */
+#ifndef MAAI_HIP_H
+#define MAAI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAAI_BF16 0
+#define MAAI_F32 1
+
+#define MAAI_ABI_VERSION 1
+
+int maai_abi_version(void);
+const char* maai_last_error(void);
+/* number of visible HIP devices, or -1 (used by the host side to fail loudly) */
+int maai_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA.
+ * Replaces nn.Conv2d inside resnet.py:20-28 (conv3x3/conv1x1), resnet.py:169
+ * (7x7 stem), nn.Linear inside multilayerPerceptron.py:12-16 (1x1 conv over a
+ * 1x1 "image"), and their autograd data gradients (same contraction with
+ * transformed weights).
+ *   x : [N, IH, IW, Cin]            NHWC
+ *   w : [Cout, KH, KW, Cin]         K-contiguous per output channel
+ *   y : [N, OH, OW, Cout]           written at (oh*out_stride+out_off_h, ow*out_stride+out_off_w)
+ *                                   for oh < OHg, ow < OWg; y += result when accumulate != 0
+ *   stats_partial (nullable): [maai_conv2d_stats_rows()][2][Cout] fp32 —
+ *       per 128-pixel block: sum and sum of squares of the fp32 results per
+ *       output channel (BatchNorm batch statistics, resnet.py:54,106-110,171).
+ * Cin % 32 == 0 (bf16) / % 16 (f32); Cout % 64 == 0.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int N, IH, IW, Cin;
+  int Cout, KH, KW;
+  int stride, pad_h, pad_w;
+  int OHg, OWg;            /* enumerated output grid */
+  int OH, OW;              /* output tensor spatial size */
+  int out_stride, out_off_h, out_off_w;
+  int accumulate;
+} maai_conv_desc;
+
+int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
+                      int dtype, void* stream);
+long long maai_conv2d_stats_rows(const maai_conv_desc* d);
+
+/* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):
+ *   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]
+ * dw is fp32 [Cout][KH][KW][Cin] and must be zeroed by the caller (split-K
+ * partial products are added with fp32 atomics). dy is dense [N,OH,OW,Cout]. */
+int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm (training) — nn.BatchNorm2d / nn.SyncBatchNorm as norm_layer
+ * (resnet.py:54,57,106-110,171,212; Contrastive_Learning.py:240-252).
+ * ------------------------------------------------------------------------ */
+/* sums[2][C] (double) = column sums of partial[rows][2][C] (fp32) */
+int maai_reduce_partials(const float* partial, long long rows, int C2, double* sums, void* stream);
+/* From (possibly all-reduced) sums over `count` samples: mean, biased var,
+ * invstd = rsqrt(var+eps); scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var updated with momentum (unbiased var), all fp32 [C].
+ * running_* may be NULL (no update). */
+int maai_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                     float* shift, int C, void* stream);
+/* eval mode: scale/shift from running statistics */
+int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* scale, float* shift, int C, void* stream);
+/* out = act(y*scale[c] + shift[c] (+ residual)); scale/shift nullable (1 / 0);
+ * relu != 0 applies max(.,0).  resnet.py:54-55,72-75,106-133; bias+ReLU of
+ * multilayerPerceptron.py:13-14 with scale == NULL. */
+int maai_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                    long long M, int C, int relu, int dtype, void* stream);
+/* backward pass 1: dz = dout * (out > 0 if relu); partial[rows][2][C] = per-block
+ * column sums of dz and dz * (y - mean[c]).  rows = maai_bn_bwd_rows(M, C, dtype).
+ * y/mean nullable (second sum left 0), out nullable when relu == 0.  Also the
+ * bias gradient of nn.Linear (column sum of dout). */
+long long maai_bn_bwd_rows(long long M, int C, int dtype);
+int maai_bn_act_bwd_reduce(const void* dout, const void* out, const void* y, const float* mean, float* partial,
+                           long long M, int C, int relu, int dtype, void* stream);
+/* From sums = [S1 = sum dz, S2 = sum dz*(y-mean)] (double, possibly all-reduced) over `count`:
+ *   dbeta = S1, dgamma = invstd*S2,
+ *   dy = k1*dz - k2 - k3*y,  k1 = gamma*invstd, k3 = k1*invstd^2*S2/count, k2 = k1*S1/count - k3*mean */
+int maai_bn_bwd_coeffs(const double* sums, double count, const float* gamma, const float* mean, const float* invstd,
+                       float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, void* stream);
+/* backward pass 2: dz = dout*(out>0); dy = k1[c]*dz - k2[c] - k3[c]*y; optional
+ * dz_out (gradient of the residual input) written too. k* nullable -> dy = dz. */
+int maai_bn_act_bwd_apply(const void* dout, const void* out, const void* y, const float* k1, const float* k2,
+                          const float* k3, void* dy, void* dz_out, long long M, int C, int relu, int dtype,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * View packing / layout (SimCLR.py:24) and pooling (resnet.py:181 variant)
+ * ------------------------------------------------------------------------ */
+/* K views [B,H,W,3] u8 (HWC) -> NHWC [B,H,W,Cpad], channel k*3+c, raw 0..255,
+ * zero padded to Cpad.  views: HOST array of K device pointers (K <= 8). */
+int maai_pack_views_u8(const void* const* views_host, int K, int B, int H, int W, int Cpad, void* out, int dtype,
+                       void* stream);
+/* Stem operand for 3-channel input: out[n,h,w, kw*4+c] = x[n,h,w+kw-3,c] (kw<7,c<3; else 0)
+ * from NCHW fp32 x [B,3,H,W] or from one u8 HWC view; turns the 7x7 stem into a 7x1 conv with Cin = 32. */
+int maai_stem_unroll_nchw_f32(const float* x, int B, int H, int W, void* out, int dtype, void* stream);
+int maai_stem_unroll_u8(const void* view, int B, int H, int W, void* out, int dtype, void* stream);
+/* NCHW fp32 <-> NHWC T (channel zero-padding on the way in, dropped on the way out) */
+int maai_nchw_f32_to_nhwc(const float* x, int B, int C, int H, int W, int Cpad, void* out, int dtype, void* stream);
+int maai_nhwc_to_nchw_f32(const void* x, int B, int C, int H, int W, int Cpad, float* out, int dtype, void* stream);
+int maai_nchw_f32_from_nhwc_grad(const void* g, int B, int C, int H, int W, int Cpad, float* out, int dtype, void* stream);
+/* adaptive average pool to PH x PW windows (H % PH == 0, W % PW == 0) */
+int maai_avgpool_fwd(const void* x, int B, int H, int W, int C, int PH, int PW, void* out, int dtype, void* stream);
+int maai_avgpool_bwd(const void* dout, int B, int H, int W, int C, int PH, int PW, void* dx, int dtype, void* stream);
+/* dtype casts: fp32 <-> T, n elements */
+int maai_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream);
+int maai_cast_to_f32(const void* src, float* dst, long long n, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * NT-Xent (Objective.py:17-81,123-125), fp32 throughout, MFMA fp32.
+ * h1,h2 [B,d] raw embeddings of this rank; Z1,Z2 [N,d] L2-normalised
+ * embeddings of all ranks (== this rank's when world == 1); row_offset =
+ * rank*B (Objective.py:55).
+ * ------------------------------------------------------------------------ */
+/* z = h / max(||h||, 1e-12) row-wise (Objective.py:42-43); inv_norm [B] saved for backward.
+ * normalize == 0 copies. */
+int maai_ntxent_normalize(const float* h, float* z, float* inv_norm, int B, int d, int normalize, void* stream);
+/* loss (1 float, zeroed by callee), logits_ab [B,N] (= z1 Z2^T / tau), lse [2][B]
+ * (row log-sum-exp of [ab,aa] and [ba,bb] with the -1e9 self mask). d % 16 == 0, d <= 512. */
+int maai_ntxent_fwd(const float* z1, const float* z2, const float* Z1, const float* Z2, float* loss, float* logits_ab,
+                    float* lse, int B, int N, int d, float temperature, int row_offset, void* stream);
+/* gradients of loss*gloss wrt z2 (always) and z1 (nullable).  local_in_gathered != 0
+ * means Z1/Z2 rows [row_offset, row_offset+B) are differentiable aliases of z1/z2
+ * (single-process semantics); 0 = gathered copies are constants (Objective.py:112-114). */
+int maai_ntxent_bwd(const float* z1, const float* z2, const float* Z1, const float* Z2, const float* lse,
+                    const float* gloss, float* dz1, float* dz2, int B, int N, int d, float temperature, int row_offset,
+                    int local_in_gathered, void* stream);
+/* through the normalisation: dh = (dz - z * (z . dz)) * inv_norm */
+int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_norm, float* dh, int B, int d,
+                              int normalize, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser (Model_Util.py:68-88: torch.optim.Adam / SGD)
+ * ------------------------------------------------------------------------ */
+int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream);
+int maai_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float weight_decay,
+                  int first_step, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Two-view augmentation replacing NVIDIA_DALI_Pipelines.py:444-480 for the
+ * north-star path: crop window -> nearest resize -> flip -> colour twist.
+ * images [B,H,W,3] u8; params [B][8] f32 = x0,y0,cw,ch,flip,brightness,contrast,saturation;
+ * out [B,OH,OW,3] u8.
+ * ------------------------------------------------------------------------ */
+int maai_augment_view_u8(const void* images, const float* params, int B, int H, int W, int OH, int OW, void* out,
+                         void* stream);
+/* Philox-free counter hash: fills params for `B` samples from (seed, view) per
+ * Contrastive_Learning.py:601-635's ranges. */
+int maai_augment_params(float* params, int B, int H, int W, unsigned long long seed, int view, float min_area,
+                        float brightness, float contrast, float saturation, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAAI_HIP_H */

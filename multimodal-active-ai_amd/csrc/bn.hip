@@ -1,0 +1,368 @@
+// BatchNorm (training / eval) + ReLU + residual, forward and backward, NHWC.
+// K5/K6 of SURVEY §2.3: nn.BatchNorm2d / nn.SyncBatchNorm as norm_layer in
+// resnet.py:54-55,72-75,106-133.  All of these are HBM-bound streaming passes:
+// 16 bytes per lane per access, channel parameters from L1/L2, fp32 maths.
+// Statistics come from the conv epilogue (conv_fwd.hip) as fp32 partial slabs
+// and are summed in fp64 here, so cross-rank SyncBN only has to all-reduce the
+// 2C doubles between maai_reduce_partials and maai_bn_finalize.
+#include "common.h"
+#include "maai_internal.h"
+
+// ---------------------------------------------------------------------------
+// partial[rows][C2] fp32 -> sums[C2] fp64 (atomic fp64 adds of per-block sums)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long long rows, int C2,
+                                                              double* __restrict__ sums, long long rows_per_block) {
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  double s = 0.0;
+  if (col < C2)
+    for (long long r = r0 + rg; r < r1; r += 4) s += (double)partial[r * C2 + col];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && col < C2) {
+    s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&sums[col], s);
+  }
+}
+
+extern "C" int maai_reduce_partials(const float* partial, long long rows, int C2, double* sums, void* stream) {
+  MAAI_CHECK_ARG(partial && sums && rows > 0 && C2 > 0, "reduce_partials: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(sums, 0, sizeof(double) * C2, st) != hipSuccess) {
+    maai_set_error("reduce_partials: memset failed");
+    return MAAI_ERR_LAUNCH;
+  }
+  long long slices = (rows + 255) / 256;
+  if (slices > 64) slices = 64;
+  const long long rpb = (rows + slices - 1) / slices;
+  dim3 grid((C2 + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
+  hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, st, partial, rows, C2, sums, rpb);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// finalize: torch.nn.BatchNorm2d training semantics
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* mean_o, float* invstd_o, float* scale_o,
+                                   float* shift_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = (float)((double)g * invstd);
+  if (mean_o) mean_o[c] = (float)mean;
+  if (invstd_o) invstd_o[c] = (float)invstd;
+  scale_o[c] = sc;
+  shift_o[c] = (float)((double)b - mean * (double)g * invstd);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int maai_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                float* invstd, float* scale, float* shift, int C, void* stream) {
+  MAAI_CHECK_ARG(sums && scale && shift && C > 0 && count > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+extern "C" int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+  MAAI_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     gamma, beta, running_mean, running_var, eps, scale, shift, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// forward apply: out = act(y*scale + shift (+ residual))
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res,
+                                                         T* __restrict__ out, long long nchunks, int cpr, int relu) {
+  constexpr int E = Vec16<T>::N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * E;
+    Vec16<T> v;
+    v.load(y + i * E);
+    float f[E];
+    v.get(f);
+    if (scale) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] *= scale[c + e];
+    }
+    if (shift) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] += shift[c + e];
+    }
+    if (res) {
+      Vec16<T> r;
+      r.load(res + i * E);
+      float g[E];
+      r.get(g);
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] += g[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    v.set(f);
+    v.store(out + i * E);
+  }
+}
+
+static inline unsigned stream_grid(long long nchunks) {
+  long long g = (nchunks + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+extern "C" int maai_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                               long long M, int C, int relu, int dtype, void* stream) {
+  MAAI_CHECK_ARG(y && out && M > 0 && C > 0, "bn_act_fwd: bad arguments");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_fwd: bad dtype");
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  MAAI_CHECK_ARG(C % E == 0, "bn_act_fwd: C must be a multiple of 8 (bf16) / 4 (f32)");
+  const long long nchunks = M * (C / E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)y, scale,
+                       shift, (const bf16_t*)residual, (bf16_t*)out, nchunks, C / E, relu);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)y, scale,
+                       shift, (const float*)residual, (float*)out, nchunks, C / E, relu);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 1: per-channel sums of dz and dz*(y-mean)
+// ---------------------------------------------------------------------------
+static inline void bwd_geometry(long long M, int C, int dtype, int* cs, int* ny, long long* rpb, long long* rows) {
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  const int cpr = C / E;
+  *cs = cpr < 256 ? cpr : 256;  // chunks (threads along C) per block slab
+  *ny = (cpr + *cs - 1) / *cs;
+  const int rpp = 256 / *cs;  // rows per pass
+  long long r = (M + 2047) / 2048;
+  if (r < 8 * rpp) r = 8 * rpp;
+  r = (r + rpp - 1) / rpp * rpp;
+  *rpb = r;
+  *rows = (M + r - 1) / r;
+}
+
+extern "C" long long maai_bn_bwd_rows(long long M, int C, int dtype) {
+  int cs, ny;
+  long long rpb, rows;
+  bwd_geometry(M, C, dtype, &cs, &ny, &rpb, &rows);
+  return rows;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            float* __restrict__ partial, long long M, int C, int cs,
+                                                            long long rpb, int relu) {
+  constexpr int E = Vec16<T>::N;
+  __shared__ float red[256 * 2 * E];
+  const int tc = threadIdx.x % cs, tr = threadIdx.x / cs, rpp = 256 / cs;
+  const int chunk = blockIdx.y * cs + tc;
+  const int c = chunk * E;
+  const bool cok = c < C;
+  float s1[E], s2[E], mu[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+    mu[e] = (mean && cok) ? mean[c + e] : 0.f;
+  }
+  const long long r0 = (long long)blockIdx.x * rpb;
+  long long r1 = r0 + rpb;
+  if (r1 > M) r1 = M;
+  if (cok) {
+    for (long long r = r0 + tr; r < r1; r += rpp) {
+      const long long off = r * C + c;
+      Vec16<T> vd;
+      vd.load(dout + off);
+      float d[E];
+      vd.get(d);
+      if (relu) {
+        Vec16<T> vo;
+        vo.load(out + off);
+        float o[E];
+        vo.get(o);
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) s1[e] += d[e];
+      if (y) {
+        Vec16<T> vy;
+        vy.load(y + off);
+        float yy[E];
+        vy.get(yy);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s2[e] += d[e] * (yy[e] - mu[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    red[(threadIdx.x * 2 + 0) * E + e] = s1[e];
+    red[(threadIdx.x * 2 + 1) * E + e] = s2[e];
+  }
+  __syncthreads();
+  // thread t < cs*2*E sums over the rpp row-threads
+  for (int o = threadIdx.x; o < cs * 2 * E; o += 256) {
+    const int tcc = o / (2 * E), rem = o - tcc * 2 * E, which = rem / E, e = rem - which * E;
+    float s = 0.f;
+    for (int k = 0; k < rpp; ++k) s += red[((k * cs + tcc) * 2 + which) * E + e];
+    const int cc = (blockIdx.y * cs + tcc) * E + e;
+    if (cc < C) partial[((long long)blockIdx.x * 2 + which) * C + cc] = s;
+  }
+}
+
+extern "C" int maai_bn_act_bwd_reduce(const void* dout, const void* out, const void* y, const float* mean,
+                                      float* partial, long long M, int C, int relu, int dtype, void* stream) {
+  MAAI_CHECK_ARG(dout && partial && M > 0 && C > 0, "bn_act_bwd_reduce: bad arguments");
+  MAAI_CHECK_ARG(!relu || out, "bn_act_bwd_reduce: relu needs the forward output");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_bwd_reduce: bad dtype");
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  MAAI_CHECK_ARG(C % E == 0, "bn_act_bwd_reduce: C must be a multiple of 8 (bf16) / 4 (f32)");
+  int cs, ny;
+  long long rpb, rows;
+  bwd_geometry(M, C, dtype, &cs, &ny, &rpb, &rows);
+  MAAI_CHECK_ARG(256 % cs == 0, "bn_act_bwd_reduce: C/vector must divide 256 or be a multiple of it");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)rows, ny);
+  if (dtype == MAAI_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
+                       (const bf16_t*)y, mean, partial, M, C, cs, rpb, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out,
+                       (const float*)y, mean, partial, M, C, cs, rpb, relu);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, double count, const float* gamma, const float* mean,
+                                     const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
+                                     int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double S1 = sums[c], S2 = sums[C + c];
+  const double is = invstd[c], g = gamma ? gamma[c] : 1.0, mu = mean[c];
+  if (dbeta) dbeta[c] = (float)S1;
+  if (dgamma) dgamma[c] = (float)(is * S2);
+  const double a = g * is;
+  const double c3 = a * is * is * S2 / count;
+  k1[c] = (float)a;
+  k3[c] = (float)c3;
+  k2[c] = (float)(a * S1 / count - c3 * mu);
+}
+
+extern "C" int maai_bn_bwd_coeffs(const double* sums, double count, const float* gamma, const float* mean,
+                                  const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
+                                  void* stream) {
+  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
+                     count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// backward pass 2: dy = k1*dz - k2 - k3*y  (and dz for the residual branch)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                           const T* __restrict__ y, const float* __restrict__ k1,
+                                                           const float* __restrict__ k2, const float* __restrict__ k3,
+                                                           T* __restrict__ dy, T* __restrict__ dz_out, long long nchunks,
+                                                           int cpr, int relu) {
+  constexpr int E = Vec16<T>::N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * E;
+    Vec16<T> vd;
+    vd.load(dout + i * E);
+    float d[E];
+    vd.get(d);
+    if (relu) {
+      Vec16<T> vo;
+      vo.load(out + i * E);
+      float o[E];
+      vo.get(o);
+#pragma unroll
+      for (int e = 0; e < E; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+    }
+    if (dz_out) {
+      Vec16<T> vz;
+      vz.set(d);
+      vz.store(dz_out + i * E);
+    }
+    if (dy) {
+      if (k1) {
+        Vec16<T> vy;
+        vy.load(y + i * E);
+        float yy[E];
+        vy.get(yy);
+#pragma unroll
+        for (int e = 0; e < E; ++e) d[e] = k1[c + e] * d[e] - k2[c + e] - k3[c + e] * yy[e];
+      }
+      Vec16<T> vr;
+      vr.set(d);
+      vr.store(dy + i * E);
+    }
+  }
+}
+
+extern "C" int maai_bn_act_bwd_apply(const void* dout, const void* out, const void* y, const float* k1, const float* k2,
+                                     const float* k3, void* dy, void* dz_out, long long M, int C, int relu, int dtype,
+                                     void* stream) {
+  MAAI_CHECK_ARG(dout && (dy || dz_out) && M > 0 && C > 0, "bn_act_bwd_apply: bad arguments");
+  MAAI_CHECK_ARG(!relu || out, "bn_act_bwd_apply: relu needs the forward output");
+  MAAI_CHECK_ARG(!k1 || (k2 && k3 && y), "bn_act_bwd_apply: k1 needs k2, k3 and y");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_bwd_apply: bad dtype");
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  MAAI_CHECK_ARG(C % E == 0, "bn_act_bwd_apply: C must be a multiple of 8 (bf16) / 4 (f32)");
+  const long long nchunks = M * (C / E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)dout,
+                       (const bf16_t*)out, (const bf16_t*)y, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dz_out, nchunks, C / E, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)dout,
+                       (const float*)out, (const float*)y, k1, k2, k3, (float*)dy, (float*)dz_out, nchunks, C / E, relu);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}

@@ -1,0 +1,293 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (K2/K3/K4 of SURVEY §2.3; also
+// the data-gradient and the MLP GEMMs, which are the same contraction).
+//
+//   y[m][co] (+)= sum_{kh,kw,ci} x[n, oh*s-ph+kh, ow*s-pw+kw, ci] * w[co][kh][kw][ci]
+//
+// GEMM view: M = N*OHg*OWg pixels, N = Cout, K = KH*KW*Cin.  NHWC activations,
+// [Cout][KH][KW][Cin] weights (K-contiguous per output channel), so every MFMA
+// A/B fragment is one 16-byte run in memory.
+//
+// Tile: BM x BN per 256-thread workgroup (4 waves as 2x2), K-step = 64 bytes per
+// row (32 bf16 / 16 f32).  Global -> registers -> LDS double buffer, one barrier
+// per K-step; LDS rows are 64 B with the st_16x32 XOR swizzle so ds_read_b128
+// fragment reads are bank-conflict free (cdna_hip_programming.md T2).
+// MFMA: v_mfma_f32_16x16x32_bf16 (bf16 storage) or 4x v_mfma_f32_16x16x4_f32
+// (f32 storage, exact fp32 — the parity mode), fp32 accumulation in both.
+// Epilogue: accumulators -> LDS -> 16-byte row-contiguous stores (full 128-B
+// lines), optional read-modify-write accumulate and strided scatter (used by
+// the stride-2 data gradients), optional per-channel sum / sum-of-squares
+// partials for BatchNorm (one deterministic slab row per M-block, no atomics).
+#include "common.h"
+#include "maai_internal.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef bf16x8 frag;
+  __device__ static __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  typedef f32x4 frag;
+  // lane group g = lane>>4 holds k = 4g+j in element j of its 16-byte chunk; MFMA j
+  // consumes element j of both operands, i.e. a consistent permutation of K.
+  __device__ static __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+struct ConvArgs {
+  const void* x;
+  const void* w;
+  void* y;
+  float* stats;
+  long long M;
+  int N, IH, IW, Cin;
+  int Cout, KH, KW;
+  int stride, pad_h, pad_w;
+  int OHg, OWg;
+  int OH, OW;
+  int ostr, ooh, oow;
+  int accumulate;
+  int nMB, nNB;
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 4 * EPC;               // 64-byte rows
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int AR = BM / 64, BR = BN / 64;  // rows staged per thread
+  constexpr int STAGE = (BM + BN) * 64;      // bytes per buffer
+  constexpr int LDC = BN + EPC;              // C-tile row pitch (elements), 16-B padded
+  typedef typename Mma<T>::frag frag_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int logical = xcd_remap(blockIdx.x, a.nMB * a.nNB);
+  const int mb = logical / a.nNB, nb = logical - mb * a.nNB;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+  const int K = a.KH * a.KW * a.Cin;
+  const int chunk = tid & 3;
+  const int r0 = tid >> 2;
+
+  // ---- per-thread row decode (fixed for the whole K loop) ----
+  long long abase[AR];
+  int ihb[AR], iwb[AR];
+  const int ohw = a.OHg * a.OWg;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const long long m = (long long)mb * BM + r0 + 64 * i;
+    if (m < a.M) {
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long long)n * ohw);
+      const int oh = rem / a.OWg, ow = rem - oh * a.OWg;
+      ihb[i] = oh * a.stride - a.pad_h;
+      iwb[i] = ow * a.stride - a.pad_w;
+      abase[i] = (((long long)n * a.IH + ihb[i]) * a.IW + iwb[i]) * a.Cin + chunk * EPC;
+    } else {
+      ihb[i] = -(1 << 28);
+      iwb[i] = -(1 << 28);
+      abase[i] = 0;
+    }
+  }
+  const T* wp[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) wp[i] = w + (long long)(nb * BN + r0 + 64 * i) * K + chunk * EPC;
+
+  uint4 ra[AR], rb[BR];
+  int kh = 0, kw = 0, c0 = 0;  // position of the NEXT tile to load
+  const int KT = K / BK;
+
+  auto load_tile = [&](int kt) {
+    const long long tapoff = ((long long)kh * a.IW + kw) * a.Cin + c0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const bool ok = (unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(x + abase[i] + tapoff) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const uint4*>(wp[i] + (long long)kt * BK);
+    c0 += BK;
+    if (c0 >= a.Cin) {
+      c0 = 0;
+      if (++kw >= a.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * 64;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = r0 + 64 * i;
+      *reinterpret_cast<uint4*>(sa + r * 64 + ((chunk ^ (((r >> 3) & 1) << 1)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int r = r0 + 64 * i;
+      *reinterpret_cast<uint4*>(sb + r * 64 + ((chunk ^ (((r >> 3) & 1) << 1)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offset inside a 16-row group (swizzled): row = lane&15, chunk = lane>>4
+  const int frow = lane & 15;
+  const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) << 1)) << 4);
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const char* sa = smem + buf * STAGE + (wm * WM) * 64 + foff;
+    const char* sb = smem + buf * STAGE + BM * 64 + (wn * WN) * 64 + foff;
+    frag_t af[TM], bfr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+    if (kt + 1 < KT) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  T* ct = reinterpret_cast<T*>(smem);
+  float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm][2][BN]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+        const int nl = wn * WN + j * 16 + (lane & 15);
+        Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
+      }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][j][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 16);
+      q += __shfl_xor(q, 16);
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lane < 16) {
+        red[(wm * 2 + 0) * BN + wn * WN + j * 16 + lane] = s;
+        red[(wm * 2 + 1) * BN + wn * WN + j * 16 + lane] = q;
+      }
+    }
+  }
+  __syncthreads();
+  if (a.stats && tid < 2 * BN) {
+    const int which = tid / BN, c = tid - which * BN;
+    a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
+  }
+  T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
+  const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
+#pragma unroll 2
+  for (int idx = tid; idx < BM * CPR; idx += 256) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const long long m = (long long)mb * BM + row;
+    if (m >= a.M) continue;
+    long long opix = m;
+    if (!dense) {
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long long)n * ohw);
+      const int oh = rem / a.OWg, ow = rem - oh * a.OWg;
+      opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
+    }
+    T* dst = y + opix * a.Cout + nb * BN + ch * EPC;
+    Vec16<T> v;
+    v.load(ct + row * LDC + ch * EPC);
+    if (a.accumulate) {
+      Vec16<T> o;
+      o.load(dst);
+      float fv[Vec16<T>::N], fo[Vec16<T>::N];
+      v.get(fv);
+      o.get(fo);
+#pragma unroll
+      for (int e = 0; e < Vec16<T>::N; ++e) fv[e] += fo[e];
+      v.set(fv);
+    }
+    v.store(dst);
+  }
+}
+
+template <typename T, int BM, int BN>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int stage = 2 * (BM + BN) * 64;
+  constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 4 * BN * (int)sizeof(float);
+  constexpr int lds = stage > epi ? stage : epi;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  const long long grid = (long long)a.nMB * a.nNB;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
+                                 int dtype, void* stream) {
+  MAAI_CHECK_ARG(d && x && w && y, "conv2d_igemm: null pointer");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_igemm: dtype must be MAAI_BF16 or MAAI_F32");
+  const int bk = dtype == MAAI_BF16 ? 32 : 16;
+  MAAI_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "conv2d_igemm: bad dims");
+  MAAI_CHECK_ARG(d->Cin % bk == 0, "conv2d_igemm: Cin must be a multiple of 32 (bf16) / 16 (f32)");
+  MAAI_CHECK_ARG(d->Cout % 64 == 0, "conv2d_igemm: Cout must be a multiple of 64");
+  MAAI_CHECK_ARG(d->OHg > 0 && d->OWg > 0 && d->out_stride >= 1, "conv2d_igemm: bad output grid");
+  MAAI_CHECK_ARG((d->OHg - 1) * d->out_stride + d->out_off_h < d->OH && (d->OWg - 1) * d->out_stride + d->out_off_w < d->OW,
+                 "conv2d_igemm: output scatter exceeds the output tensor");
+  ConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.stats = stats_partial;
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+  a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OHg = d->OHg; a.OWg = d->OWg;
+  a.OH = d->OH; a.OW = d->OW; a.ostr = d->out_stride; a.ooh = d->out_off_h; a.oow = d->out_off_w;
+  a.accumulate = d->accumulate;
+  a.M = (long long)d->N * d->OHg * d->OWg;
+  a.nMB = (int)((a.M + 127) / 128);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (d->Cout % 128 == 0) {
+    a.nNB = d->Cout / 128;
+    return dtype == MAAI_BF16 ? launch_conv<bf16_t, 128, 128>(a, st) : launch_conv<float, 128, 128>(a, st);
+  }
+  a.nNB = d->Cout / 64;
+  return dtype == MAAI_BF16 ? launch_conv<bf16_t, 128, 64>(a, st) : launch_conv<float, 128, 64>(a, st);
+}
+
+extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d) {
+  if (!d) return 0;
+  const long long M = (long long)d->N * d->OHg * d->OWg;
+  return (M + 127) / 128;
+}

@@ -1,0 +1,231 @@
+// Weight gradient of the implicit-GEMM convolution (autograd of nn.Conv2d /
+// nn.Linear on the path: resnet.py:20-28,169; multilayerPerceptron.py:12-16).
+//
+//   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]
+//
+// GEMM view: rows = Cout, cols = (tap, Cin), contraction over the N*OH*OW
+// pixels, split across workgroups (split-K) and added with fp32 atomics.
+// Both operands are stored pixel-major (NHWC), i.e. the contraction index is
+// the SLOW index of both — the MFMA wants it fastest.  bf16: tiles are staged
+// pixel-major in LDS and the fragments come out transposed through
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10): lane group g, read h, row q
+// <-> pixel 16h+4g+q, so one wave-instruction's 32 lanes cover 8 consecutive
+// pixel rows and, with a row pitch of 2*BC+32 bytes, all 64 banks exactly once.
+// f32: v_mfma_f32_16x16x4_f32 takes one k per lane group, which is a plain
+// ds_read_b32 of the pixel-major tile (pitch BC+16 words, conflict-free).
+#include "common.h"
+#include "maai_internal.h"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int M;  // N*OH*OW
+  int N, IH, IW, Cin, Cout, KH, KW, stride, pad_h, pad_w, OH, OW;
+  int nCoB, nCiB, nTap;
+  int pix_per_split;
+};
+
+template <typename T, int BCO, int BCI>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int PK = BF ? 32 : 16;  // pixels per K-step
+  constexpr int PITCH_Y = BF ? (2 * BCO + 32) : (4 * (BCO + 16));  // bytes
+  constexpr int PITCH_X = BF ? (2 * BCI + 32) : (4 * (BCI + 16));
+  constexpr int TILE_Y = PK * PITCH_Y, TILE_X = PK * PITCH_X, STAGE = TILE_Y + TILE_X;
+  constexpr int CPRY = BCO / EPC, CPRX = BCI / EPC;
+  constexpr int NLY = (PK * CPRY + 255) / 256, NLX = (PK * CPRX + 255) / 256;
+  constexpr int WCO = BCO / 2, WCI = BCI / 2, TM = WCO / 16, TN = WCI / 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  int id = blockIdx.x;
+  const int tap = id % a.nTap;
+  id /= a.nTap;
+  const int cib = id % a.nCiB, cob = id / a.nCiB;
+  const int kh = tap / a.KW, kw = tap - kh * a.KW;
+  const int co0 = cob * BCO, ci0 = cib * BCI;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const int ps = blockIdx.y * a.pix_per_split;
+  int pe = ps + a.pix_per_split;
+  if (pe > a.M) pe = a.M;
+  const int ohw = a.OH * a.OW;
+
+  uint4 ry[NLY], rx[NLX];
+  auto load_tile = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPRY, ch = idx - row * CPRY;
+      const int m = p0 + row;
+      ry[i] = (row < PK && m < pe) ? *reinterpret_cast<const uint4*>(dy + (long long)m * a.Cout + co0 + ch * EPC)
+                                   : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPRX, ch = idx - row * CPRX;
+      const int m = p0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < PK && m < pe) {
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        const int ih = oh * a.stride - a.pad_h + kh, iw = ow * a.stride - a.pad_w + kw;
+        if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+          v = *reinterpret_cast<const uint4*>(x + (((long long)n * a.IH + ih) * a.IW + iw) * a.Cin + ci0 + ch * EPC);
+      }
+      rx[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* sy = smem + buf * STAGE;
+    char* sx = sy + TILE_Y;
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPRY, ch = idx - row * CPRY;
+      if (row < PK) *reinterpret_cast<uint4*>(sy + row * PITCH_Y + ch * 16) = ry[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPRX, ch = idx - row * CPRX;
+      if (row < PK) *reinterpret_cast<uint4*>(sx + row * PITCH_X + ch * 16) = rx[i];
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, g = lane >> 4;
+  const int nsteps = (pe - ps + PK - 1) / PK;
+  if (nsteps > 0) {
+    load_tile(ps);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_tile(ps + (s + 1) * PK);
+    const char* sy = smem + buf * STAGE;
+    const char* sx = sy + TILE_Y;
+    if constexpr (BF) {
+      // transposed fragment reads: lane (q = li>>2, p = li&3) addresses row 16h+4g+q, columns cb+4p..cb+4p+3
+      bf16x8 af[TM], bfr[TN];
+      const int q = li >> 2, p = li & 3;
+      const int rowoff0 = (4 * g + q);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int cb = wm * WCO + i * 16;
+        const char* base = sy + rowoff0 * PITCH_Y + (cb + 4 * p) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base + 16 * PITCH_Y));
+        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cb = wn * WCI + j * 16;
+        const char* base = sx + rowoff0 * PITCH_X + (cb + 4 * p) * 2;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base + 16 * PITCH_X));
+        bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < PK / 4; ++ks) {
+        float af[TM], bfr[TN];
+        const int prow = 4 * ks + g;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float*>(sy + prow * PITCH_Y + (wm * WCO + i * 16 + li) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const float*>(sx + prow * PITCH_X + (wn * WCI + j * 16 + li) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (nsteps <= 0) return;
+  // epilogue: fp32 atomics; C layout row(co) = 4g + r, col(ci) = li
+  const int ntap = a.KH * a.KW;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * WCO + i * 16 + 4 * g + r;
+        const int ci = ci0 + wn * WCI + j * 16 + li;
+        atomicAdd(a.dw + ((long long)co * ntap + tap) * a.Cin + ci, acc[i][j][r]);
+      }
+}
+
+template <typename T, int BCO, int BCI>
+static int launch_wgrad(WgradArgs a, hipStream_t st) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int PK = BF ? 32 : 16;
+  constexpr int PITCH_Y = BF ? (2 * BCO + 32) : (4 * (BCO + 16));
+  constexpr int PITCH_X = BF ? (2 * BCI + 32) : (4 * (BCI + 16));
+  constexpr int lds = 2 * PK * (PITCH_Y + PITCH_X);
+  a.nCoB = a.Cout / BCO;
+  a.nCiB = a.Cin / BCI;
+  a.nTap = a.KH * a.KW;
+  const long long tiles = (long long)a.nCoB * a.nCiB * a.nTap;
+  const int ksteps = (a.M + PK - 1) / PK;
+  long long split = (2048 + tiles - 1) / tiles;
+  if (split > ksteps / 4) split = ksteps / 4;
+  if (split < 1) split = 1;
+  if (split > 65535) split = 65535;
+  const int steps_per = (int)((ksteps + split - 1) / split);
+  a.pix_per_split = steps_per * PK;
+  const int ny = (a.M + a.pix_per_split - 1) / a.pix_per_split;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+template <typename T>
+static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
+  const bool co128 = a.Cout % 128 == 0;
+  if (a.Cin % 128 == 0) return co128 ? launch_wgrad<T, 128, 128>(a, st) : launch_wgrad<T, 64, 128>(a, st);
+  if (a.Cin % 64 == 0) return co128 ? launch_wgrad<T, 128, 64>(a, st) : launch_wgrad<T, 64, 64>(a, st);
+  return co128 ? launch_wgrad<T, 128, 32>(a, st) : launch_wgrad<T, 64, 32>(a, st);
+}
+
+extern "C" int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype, void* stream) {
+  MAAI_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: null pointer");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_wgrad: dtype must be MAAI_BF16 or MAAI_F32");
+  MAAI_CHECK_ARG(d->Cin % 32 == 0, "conv2d_wgrad: Cin must be a multiple of 32");
+  MAAI_CHECK_ARG(d->Cout % 64 == 0, "conv2d_wgrad: Cout must be a multiple of 64");
+  MAAI_CHECK_ARG(d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->OHg == d->OH && d->OWg == d->OW,
+                 "conv2d_wgrad: dy must be the dense output grid");
+  const long long M = (long long)d->N * d->OH * d->OW;
+  MAAI_CHECK_ARG(M > 0 && M < (1ll << 31), "conv2d_wgrad: pixel count must fit 31 bits");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw; a.M = (int)M;
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+  a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OH = d->OH; a.OW = d->OW;
+  a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return dtype == MAAI_BF16 ? dispatch_wgrad<bf16_t>(a, st) : dispatch_wgrad<float>(a, st);
+}

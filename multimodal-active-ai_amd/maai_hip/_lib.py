@@ -1,0 +1,92 @@
+"""ctypes binding of libmaai_hip.so (the C ABI in include/maai_hip.h).
+
+The library is the product: there is NO fallback.  ``lib()`` raises if the
+shared object is missing, and every compute wrapper in ``kernels.py`` raises
+if the tensors are not on a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmaai_hip.so")
+
+BF16, F32 = 0, 1
+
+c_p, c_i, c_ll, c_f, c_d, c_ull = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_ulonglong
+
+
+class ConvDesc(C.Structure):
+    """maai_conv_desc"""
+    _fields_ = [(n, c_i) for n in ("N", "IH", "IW", "Cin", "Cout", "KH", "KW", "stride", "pad_h", "pad_w", "OHg", "OWg",
+                                   "OH", "OW", "out_stride", "out_off_h", "out_off_w", "accumulate")]
+
+
+_P_DESC = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/maai_hip.h line by line
+SIGNATURES = {
+    "maai_abi_version": (c_i, []),
+    "maai_last_error": (C.c_char_p, []),
+    "maai_device_count": (c_i, []),
+    "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_conv2d_stats_rows": (c_ll, [_P_DESC]),
+    "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
+    "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),
+    "maai_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
+    "maai_bn_act_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "maai_bn_bwd_rows": (c_ll, [c_ll, c_i, c_i]),
+    "maai_bn_act_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "maai_bn_bwd_coeffs": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_act_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "maai_pack_views_u8": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_stem_unroll_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_stem_unroll_u8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_nchw_f32_to_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_nhwc_to_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_nchw_f32_from_nhwc_grad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_avgpool_fwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_avgpool_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "maai_cast_from_f32": (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    "maai_cast_to_f32": (c_i, [c_p, c_p, c_ll, c_i, c_p]),
+    "maai_ntxent_normalize": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "maai_ntxent_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "maai_ntxent_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    "maai_ntxent_normalize_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
+    "maai_augment_view_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "maai_augment_params": (c_i, [c_p, c_i, c_i, c_i, c_ull, c_i, c_f, c_f, c_f, c_f, c_p]),
+}
+
+_LIB = None
+
+
+class MaaiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MaaiError(
+                "libmaai_hip.so is missing (%s). Build it with `python multimodal-active-ai_amd/build.py` "
+                "(needs hipcc); there is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        if handle.maai_abi_version() != 1:
+            raise MaaiError("libmaai_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().maai_last_error()
+        raise MaaiError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,320 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs with torch, pass raw
+device pointers + the current HIP stream.  Internal layout: activations NHWC
+``[N,H,W,C]`` contiguous, weights ``[Cout,KH,KW,Cin]``; storage dtype
+torch.bfloat16 (production) or torch.float32 (exact-fp32 parity mode).
+
+No fallback: every wrapper raises ``MaaiError`` for non-HIP tensors.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import BF16, F32, ConvDesc, MaaiError, check, lib
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise MaaiError("unsupported storage dtype %s (bf16 or f32)" % t.dtype)
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MaaiError("the HIP path needs tensors on a HIP device (got %s); there is no CPU fallback" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise MaaiError("tensor must be contiguous")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------
+def conv_out_hw(ih, iw, kh, kw, stride, pad_h, pad_w):
+    return (ih + 2 * pad_h - kh) // stride + 1, (iw + 2 * pad_w - kw) // stride + 1
+
+
+def make_desc(x, w, stride, pad_h, pad_w, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False):
+    n, ih, iw, cin = x.shape
+    cout, kh, kw, cin_w = w.shape
+    if cin != cin_w:
+        raise MaaiError("conv2d: Cin mismatch %d vs %d" % (cin, cin_w))
+    oh, ow = conv_out_hw(ih, iw, kh, kw, stride, pad_h, pad_w) if grid_hw is None else grid_hw
+    toh, tow = (oh, ow) if out_hw is None else out_hw
+    return ConvDesc(n, ih, iw, cin, cout, kh, kw, stride, pad_h, pad_w, oh, ow, toh, tow, out_stride, out_off[0], out_off[1],
+                    1 if accumulate else 0)
+
+
+def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None, out_hw=None, out_stride=1,
+           out_off=(0, 0), accumulate=False):
+    """y = conv(x, w) (NHWC / KHWC).  Returns y or (y, stats_partial[rows,2,Cout])."""
+    _gpu(x, w, out)
+    if x.dtype != w.dtype:
+        raise MaaiError("conv2d: x and w must share the storage dtype")
+    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
+    if out is None:
+        if accumulate or out_stride != 1:
+            raise MaaiError("conv2d: scatter/accumulate needs an explicit output tensor")
+        out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
+    part = None
+    if stats:
+        rows = lib().maai_conv2d_stats_rows(C.byref(d))
+        part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
+    check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _dt(x), _stream()), "maai_conv2d_igemm")
+    return (out, part) if stats else out
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
+    """dw[Cout,KH,KW,Cin] fp32 for y = conv(x, w); dy dense [N,OH,OW,Cout]."""
+    _gpu(x, dy)
+    n, ih, iw, cin = x.shape
+    _, oh, ow, cout = dy.shape
+    d = ConvDesc(n, ih, iw, cin, cout, kh, kw, stride, pad_h, pad_w, oh, ow, oh, ow, 1, 0, 0, 0)
+    dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
+    check(lib().maai_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), _stream()), "maai_conv2d_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------
+# batch norm
+# ----------------------------------------------------------------------------
+def reduce_partials(partial):
+    """[rows, ...] fp32 -> fp64 column sums (flattened trailing dims)."""
+    _gpu(partial)
+    rows = partial.shape[0]
+    c2 = partial.numel() // rows
+    sums = torch.empty(c2, dtype=torch.float64, device=partial.device)
+    check(lib().maai_reduce_partials(_p(partial), rows, c2, _p(sums), _stream()), "maai_reduce_partials")
+    return sums
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps):
+    c = sums.numel() // 2
+    dev = sums.device
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    check(lib().maai_bn_finalize(_p(sums), float(count), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                 float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(shift), c, _stream()),
+          "maai_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    _gpu(running_mean, running_var)
+    c = running_mean.numel()
+    scale, shift = (torch.empty(c, dtype=torch.float32, device=running_mean.device) for _ in range(2))
+    check(lib().maai_bn_eval_coeffs(_p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(scale), _p(shift),
+                                    c, _stream()), "maai_bn_eval_coeffs")
+    return scale, shift
+
+
+def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None):
+    _gpu(y, scale, shift, residual, out)
+    c = y.shape[-1]
+    m = y.numel() // c
+    if out is None:
+        out = torch.empty_like(y)
+    check(lib().maai_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(residual), _p(out), m, c, 1 if relu else 0, _dt(y), _stream()),
+          "maai_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd_reduce(dout, out, y, mean, relu):
+    """fp64 sums [2C]: sum dz, sum dz*(y-mean)."""
+    _gpu(dout, out, y, mean)
+    c = dout.shape[-1]
+    m = dout.numel() // c
+    rows = lib().maai_bn_bwd_rows(m, c, _dt(dout))
+    part = torch.empty((rows, 2, c), dtype=torch.float32, device=dout.device)
+    if y is None:
+        part.zero_()
+    check(lib().maai_bn_act_bwd_reduce(_p(dout), _p(out), _p(y), _p(mean), _p(part), m, c, 1 if relu else 0, _dt(dout),
+                                       _stream()), "maai_bn_act_bwd_reduce")
+    return reduce_partials(part)
+
+
+def bn_bwd_coeffs(sums, count, gamma, mean, invstd):
+    c = mean.numel()
+    dev = mean.device
+    dgamma, dbeta, k1, k2, k3 = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(5))
+    check(lib().maai_bn_bwd_coeffs(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
+                                   _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs")
+    return dgamma, dbeta, k1, k2, k3
+
+
+def bn_act_bwd_apply(dout, out, y, k1, k2, k3, relu, want_dy=True, want_dz=False):
+    _gpu(dout, out, y, k1, k2, k3)
+    c = dout.shape[-1]
+    m = dout.numel() // c
+    dy = torch.empty_like(dout) if want_dy else None
+    dz = torch.empty_like(dout) if want_dz else None
+    check(lib().maai_bn_act_bwd_apply(_p(dout), _p(out), _p(y), _p(k1), _p(k2), _p(k3), _p(dy), _p(dz), m, c,
+                                      1 if relu else 0, _dt(dout), _stream()), "maai_bn_act_bwd_apply")
+    return dy, dz
+
+
+# ----------------------------------------------------------------------------
+# layout / pooling / casts
+# ----------------------------------------------------------------------------
+def pack_views_u8(views, cpad, dtype):
+    for v in views:
+        _gpu(v)
+        if v.dtype != torch.uint8:
+            raise MaaiError("pack_views_u8: views must be uint8 [B,H,W,3]")
+    b, h, w, c3 = views[0].shape
+    if c3 != 3:
+        raise MaaiError("pack_views_u8: last dim must be 3")
+    out = torch.empty((b, h, w, cpad), dtype=dtype, device=views[0].device)
+    arr = (C.c_void_p * len(views))(*[v.data_ptr() for v in views])
+    check(lib().maai_pack_views_u8(arr, len(views), b, h, w, cpad, _p(out), _dt(out), _stream()), "maai_pack_views_u8")
+    return out
+
+
+def stem_unroll(x, dtype):
+    """x: NCHW fp32 [B,3,H,W] or u8 HWC [B,H,W,3] -> [B,H,W,32] (kw-unrolled stem operand)."""
+    _gpu(x)
+    if x.dtype == torch.uint8:
+        b, h, w, _ = x.shape
+        out = torch.empty((b, h, w, 32), dtype=dtype, device=x.device)
+        check(lib().maai_stem_unroll_u8(_p(x), b, h, w, _p(out), _dt(out), _stream()), "maai_stem_unroll_u8")
+    else:
+        b, c, h, w = x.shape
+        if c != 3 or x.dtype != torch.float32:
+            raise MaaiError("stem_unroll: expects fp32 NCHW with 3 channels")
+        out = torch.empty((b, h, w, 32), dtype=dtype, device=x.device)
+        check(lib().maai_stem_unroll_nchw_f32(_p(x), b, h, w, _p(out), _dt(out), _stream()), "maai_stem_unroll_nchw_f32")
+    return out
+
+
+def nchw_to_nhwc(x, cpad, dtype):
+    _gpu(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, cpad), dtype=dtype, device=x.device)
+    check(lib().maai_nchw_f32_to_nhwc(_p(x), b, c, h, w, cpad, _p(out), _dt(out), _stream()), "maai_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, c):
+    _gpu(x)
+    b, h, w, cpad = x.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib().maai_nhwc_to_nchw_f32(_p(x), b, c, h, w, cpad, _p(out), _dt(x), _stream()), "maai_nhwc_to_nchw_f32")
+    return out
+
+
+def avgpool_fwd(x, ph, pw):
+    _gpu(x)
+    b, h, w, c = x.shape
+    out = torch.empty((b, ph, pw, c), dtype=x.dtype, device=x.device)
+    check(lib().maai_avgpool_fwd(_p(x), b, h, w, c, ph, pw, _p(out), _dt(x), _stream()), "maai_avgpool_fwd")
+    return out
+
+
+def avgpool_bwd(dout, h, w):
+    _gpu(dout)
+    b, ph, pw, c = dout.shape
+    dx = torch.empty((b, h, w, c), dtype=dout.dtype, device=dout.device)
+    check(lib().maai_avgpool_bwd(_p(dout), b, h, w, c, ph, pw, _p(dx), _dt(dout), _stream()), "maai_avgpool_bwd")
+    return dx
+
+
+def cast_from_f32(src, dtype):
+    _gpu(src)
+    if dtype == torch.float32:
+        return src
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib().maai_cast_from_f32(_p(src), _p(out), src.numel(), _dt(out), _stream()), "maai_cast_from_f32")
+    return out
+
+
+def cast_to_f32(src):
+    _gpu(src)
+    if src.dtype == torch.float32:
+        return src
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib().maai_cast_to_f32(_p(src), _p(out), src.numel(), _dt(src), _stream()), "maai_cast_to_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# NT-Xent
+# ----------------------------------------------------------------------------
+def ntxent_normalize(h, normalize=True):
+    _gpu(h)
+    b, d = h.shape
+    z = torch.empty_like(h)
+    inv = torch.empty(b, dtype=torch.float32, device=h.device)
+    check(lib().maai_ntxent_normalize(_p(h), _p(z), _p(inv), b, d, 1 if normalize else 0, _stream()), "maai_ntxent_normalize")
+    return z, inv
+
+
+def ntxent_fwd(z1, z2, Z1, Z2, temperature, row_offset):
+    _gpu(z1, z2, Z1, Z2)
+    b, d = z1.shape
+    n = Z1.shape[0]
+    loss = torch.empty((), dtype=torch.float32, device=z1.device)
+    logits = torch.empty((b, n), dtype=torch.float32, device=z1.device)
+    lse = torch.empty((4, b), dtype=torch.float32, device=z1.device)
+    check(lib().maai_ntxent_fwd(_p(z1), _p(z2), _p(Z1), _p(Z2), _p(loss), _p(logits), _p(lse), b, n, d, float(temperature),
+                                int(row_offset), _stream()), "maai_ntxent_fwd")
+    return loss, logits, lse
+
+
+def ntxent_bwd(z1, z2, Z1, Z2, lse, gloss, temperature, row_offset, local_in_gathered, want_dz1):
+    _gpu(z1, z2, Z1, Z2, lse, gloss)
+    b, d = z1.shape
+    n = Z1.shape[0]
+    dz2 = torch.empty_like(z2)
+    dz1 = torch.empty_like(z1) if want_dz1 else None
+    check(lib().maai_ntxent_bwd(_p(z1), _p(z2), _p(Z1), _p(Z2), _p(lse), _p(gloss), _p(dz1), _p(dz2), b, n, d,
+                                float(temperature), int(row_offset), 1 if local_in_gathered else 0, _stream()),
+          "maai_ntxent_bwd")
+    return dz1, dz2
+
+
+def ntxent_normalize_bwd(z, dz, inv, normalize=True):
+    _gpu(z, dz, inv)
+    b, d = z.shape
+    dh = torch.empty_like(z)
+    check(lib().maai_ntxent_normalize_bwd(_p(z), _p(dz), _p(inv), _p(dh), b, d, 1 if normalize else 0, _stream()),
+          "maai_ntxent_normalize_bwd")
+    return dh
+
+
+# ----------------------------------------------------------------------------
+# optimiser / augmentation
+# ----------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    _gpu(p, g, m, v)
+    check(lib().maai_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                               int(step), float(grad_scale), _stream()), "maai_adam_step")
+
+
+def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step):
+    _gpu(p, g, mom)
+    check(lib().maai_sgd_step(_p(p), _p(g), _p(mom), p.numel(), float(lr), float(momentum), float(weight_decay),
+                              1 if first_step else 0, _stream()), "maai_sgd_step")
+
+
+def augment_view_u8(images, params, oh, ow):
+    _gpu(images, params)
+    b, h, w, _ = images.shape
+    out = torch.empty((b, oh, ow, 3), dtype=torch.uint8, device=images.device)
+    check(lib().maai_augment_view_u8(_p(images), _p(params), b, h, w, oh, ow, _p(out), _stream()), "maai_augment_view_u8")
+    return out
+
+
+def augment_params(b, h, w, seed, view, device, min_area=0.1, brightness=0.8, contrast=0.8, saturation=0.8):
+    params = torch.empty((b, 8), dtype=torch.float32, device=device)
+    _gpu(params)
+    check(lib().maai_augment_params(_p(params), b, h, w, int(seed), int(view), float(min_area), float(brightness),
+                                    float(contrast), float(saturation), _stream()), "maai_augment_params")
+    return params

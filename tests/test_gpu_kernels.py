@@ -1,0 +1,386 @@
+"""Kernel-level parity on a real MI355X: every entry point of the C ABI against
+the CPU oracle / a plain fp64 torch reference on the same seeded inputs.
+Tolerances: bf16 storage = 2^-8 relative on outputs that are rounded to bf16
+(inputs are pre-rounded to bf16, products exact, fp32 accumulate); f32 storage
+(exact-fp32 MFMA) = 2e-5 relative; integer/u8 work bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import simclr_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from maai_hip import kernels
+    return kernels
+
+
+def rb(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def khwc(w, dtype):
+    return w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+def tol(dtype):
+    return dict(rtol=1.0 / 128, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=3e-5, atol=3e-5)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad
+    (2, 64, 30, 30, 256, 1, 1, 0),
+    (3, 256, 15, 15, 64, 1, 1, 0),
+    (2, 64, 30, 30, 64, 3, 1, 1),
+    (2, 128, 30, 30, 128, 3, 2, 1),
+    (3, 128, 15, 15, 128, 3, 2, 1),     # odd extent, stride 2 (15 -> 8)
+    (2, 256, 15, 15, 512, 1, 2, 0),     # downsample 1x1 stride 2
+    (2, 32, 30, 30, 64, 7, 1, 3),       # padded-channel 7x7 stem
+    (1, 512, 4, 4, 2048, 1, 1, 0),      # M = 16 << tile
+    (5, 64, 9, 7, 192, 3, 1, 1),        # ragged everything, Cout = 3*64
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_and_stats(K, case, dtype):
+    n, cin, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    if dtype == torch.bfloat16:
+        x, wt = rb(x), rb(wt)
+    ref = F.conv2d(x.double(), wt.double(), None, s, p)
+    y, part = K.conv2d(nhwc(x, dtype), khwc(wt, dtype), s, p, p, stats=True)
+    torch.cuda.synchronize()
+    got = from_nhwc(y)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), **tol(dtype))
+    sums = K.reduce_partials(part).cpu()
+    m = n * ref.shape[2] * ref.shape[3]
+    np.testing.assert_allclose(sums[:cout].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=2e-3 * m ** 0.5)
+    np.testing.assert_allclose(sums[cout:].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=1e-3)
+
+
+def test_conv_exact_integer_layout(K):
+    """Integer-valued operands: every product and sum is exact in bf16/fp32, so any
+    fragment-layout or swizzle mistake shows as a hard mismatch (asymmetric data)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (2, 64, 13, 11), generator=g).float()
+    w = torch.randint(-2, 3, (128, 64, 3, 3), generator=g).float()
+    ref = F.conv2d(x, w, None, 1, 1)
+    for dtype in (torch.bfloat16, torch.float32):
+        y = K.conv2d(nhwc(x, dtype), khwc(w, dtype), 1, 1, 1)
+        got = from_nhwc(y)
+        if dtype == torch.float32:
+            assert torch.equal(got, ref)
+        else:
+            assert torch.equal(got, rb(ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_conv_scatter_accumulate(K, dtype):
+    """strided scatter + read-modify-write epilogue (used by stride-2 data gradients)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    wt = torch.randn(128, 64, 1, 1, generator=g) / 8
+    base = torch.randn(2, 128, 15, 15, generator=g)
+    if dtype == torch.bfloat16:
+        x, wt, base = rb(x), rb(wt), rb(base)
+    out = nhwc(base, dtype)
+    K.conv2d(nhwc(x, dtype), khwc(wt, dtype), 1, 0, 0, out=out, grid_hw=(8, 8), out_hw=(15, 15), out_stride=2, out_off=(0, 0),
+             accumulate=True)
+    ref = base.clone().double()
+    ref[:, :, 0::2, 0::2] += F.conv2d(x.double(), wt.double())
+    np.testing.assert_allclose(from_nhwc(out).numpy(), ref.float().numpy(), **tol(dtype))
+
+
+WGRAD_CASES = [
+    (2, 64, 30, 30, 256, 1, 1, 0),
+    (2, 64, 30, 30, 64, 3, 1, 1),
+    (3, 128, 15, 15, 128, 3, 2, 1),
+    (2, 256, 15, 15, 512, 1, 2, 0),
+    (2, 32, 30, 30, 64, 7, 1, 3),
+    (4, 512, 4, 4, 128, 1, 1, 0),
+    (3, 64, 9, 7, 192, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(K, case, dtype):
+    n, cin, h, w, cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 997)
+    x = torch.randn(n, cin, h, w, generator=g)
+    oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    dy = torch.randn(n, cout, oh, ow, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = rb(x), rb(dy)
+    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, s, p).backward(dy.double())
+    dw = K.conv2d_wgrad(nhwc(x, dtype), nhwc(dy, dtype), k, k, s, p, p)
+    got = dw.cpu().permute(0, 3, 1, 2)
+    scale = wt.grad.abs().max().item()
+    np.testing.assert_allclose(got.numpy(), wt.grad.float().numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
+
+
+def test_wgrad_exact_integer_layout(K):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(-2, 3, (2, 64, 6, 5), generator=g).float()
+    dy = torch.randint(-2, 3, (2, 128, 6, 5), generator=g).float()
+    wt = torch.zeros(128, 64, 3, 3, requires_grad=True)
+    F.conv2d(x, wt, None, 1, 1).backward(dy)
+    for dtype in (torch.bfloat16, torch.float32):
+        dw = K.conv2d_wgrad(nhwc(x, dtype), nhwc(dy, dtype), 3, 3, 1, 1, 1)
+        assert torch.equal(dw.cpu().permute(0, 3, 1, 2), wt.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(4, 64, 15, 15), (2, 256, 8, 8), (3, 2048, 4, 4), (16, 1024, 1, 1)])
+@pytest.mark.parametrize("res", [False, True])
+def test_bn_fwd_bwd(K, shape, dtype, res):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    y = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    r = torch.randn(n, c, h, w, generator=g) if res else None
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.1
+    dout = torch.randn(n, c, h, w, generator=g)
+    if dtype == torch.bfloat16:
+        y, dout = rb(y), rb(dout)
+        r = rb(r) if res else None
+    # reference (fp64 autograd, torch BatchNorm semantics)
+    yd = y.double().requires_grad_(True)
+    rd = r.double().requires_grad_(True) if res else None
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    o = F.batch_norm(yd, rm, rv, gd, bd, True, 0.1, 1e-5)
+    o = F.relu(o + rd) if res else F.relu(o)
+    o.backward(dout.double())
+    # HIP: statistics from a conv-epilogue-shaped partial slab (one row here)
+    M = n * h * w
+    ynh = nhwc(y, dtype)
+    part = torch.stack([ynh.float().sum(dim=(0, 1, 2)), (ynh.float() ** 2).sum(dim=(0, 1, 2))]).reshape(1, 2, c).contiguous()
+    sums = K.reduce_partials(part)
+    rmg, rvg = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    mean, invstd, scale, shift = K.bn_finalize(sums, M, gamma.cuda(), beta.cuda(), rmg, rvg, 0.1, 1e-5)
+    np.testing.assert_allclose(rmg.cpu().numpy(), rm.float().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rvg.cpu().numpy(), rv.float().numpy(), rtol=1e-4, atol=1e-5)
+    out = K.bn_act_fwd(ynh, scale, shift, nhwc(r, dtype) if res else None, True)
+    np.testing.assert_allclose(from_nhwc(out).numpy(), o.detach().float().numpy(), **tol(dtype))
+    # backward with the reference's forward output as the ReLU mask source (avoids flips at 0)
+    out_ref = nhwc(o.detach().float(), dtype)
+    dnh = nhwc(dout, dtype)
+    s2 = K.bn_act_bwd_reduce(dnh, out_ref, ynh, mean, True)
+    dgamma, dbeta, k1, k2, k3 = K.bn_bwd_coeffs(s2, M, gamma.cuda(), mean, invstd)
+    dy, dz = K.bn_act_bwd_apply(dnh, out_ref, ynh, k1, k2, k3, True, True, res)
+    gs = gd.grad.abs().max().item()
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gd.grad.float().numpy(), rtol=2e-3, atol=2e-3 * gs)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), bd.grad.float().numpy(), rtol=2e-3, atol=2e-3 * bd.grad.abs().max().item())
+    np.testing.assert_allclose(from_nhwc(dy).numpy(), yd.grad.float().numpy(), rtol=1e-2 if dtype == torch.bfloat16 else 1e-4,
+                               atol=2e-2 if dtype == torch.bfloat16 else 1e-4)
+    if res:
+        np.testing.assert_allclose(from_nhwc(dz).numpy(), rd.grad.float().numpy(), **tol(dtype))
+
+
+def test_bn_eval_coeffs(K):
+    c = 96
+    g = torch.Generator().manual_seed(3)
+    gamma, beta, rm, rv = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g), torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.1
+    scale, shift = K.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    x = torch.randn(4, c, 3, 3, generator=g)
+    ref = F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    got = x * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None]
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# NT-Xent
+# ---------------------------------------------------------------------------
+def _ntxent_hip(K, h1, h2, tau, normalize=True, rank=0, world=1, gathered=None, want_dz1=False):
+    h1g, h2g = h1.cuda(), h2.cuda()
+    z1, inv1 = K.ntxent_normalize(h1g, normalize)
+    z2, inv2 = K.ntxent_normalize(h2g, normalize)
+    if world > 1:
+        Z1, Z2 = gathered[0].cuda().contiguous(), gathered[1].cuda().contiguous()
+    else:
+        Z1, Z2 = z1, z2
+    b = h1.shape[0]
+    loss, logits, lse = K.ntxent_fwd(z1, z2, Z1, Z2, tau, rank * b)
+    one = torch.ones((), device="cuda")
+    dz1, dz2 = K.ntxent_bwd(z1, z2, Z1, Z2, lse, one, tau, rank * b, world == 1, want_dz1)
+    dh2 = K.ntxent_normalize_bwd(z2, dz2, inv2, normalize)
+    dh1 = K.ntxent_normalize_bwd(z1, dz1, inv1, normalize) if want_dz1 else None
+    torch.cuda.synchronize()
+    return loss.cpu(), logits.cpu(), dh2.cpu(), (dh1.cpu() if want_dz1 else None)
+
+
+@pytest.mark.parametrize("tag", ["b8", "b16", "b64", "b33"])
+def test_ntxent_golden_single(K, golden_dir, tag):
+    G = np.load(os.path.join(golden_dir, "ntxent_single.npz"))
+    b, d, tau, seed = G[f"{tag}_cfg"]
+    b, d, seed = int(b), int(d), int(seed)
+    torch.manual_seed(seed)
+    h1, h2 = torch.randn(b, d), torch.randn(b, d)
+    loss, logits, dh2, _ = _ntxent_hip(K, h1, h2, float(tau))
+    np.testing.assert_allclose(loss.item(), G[f"{tag}_loss"], rtol=2e-6)
+    np.testing.assert_allclose(logits.numpy(), G[f"{tag}_logits"], rtol=1e-5, atol=2e-6)
+    # golden dh2: h1 detached (train loop), gradient through both operands of bb and the ab/ba pair
+    np.testing.assert_allclose(dh2.numpy(), G[f"{tag}_dh2"], rtol=2e-4, atol=2e-7)
+    # both inputs differentiable
+    _, _, dh2b, dh1b = _ntxent_hip(K, h1, h2, float(tau), want_dz1=True)
+    np.testing.assert_allclose(dh2b.numpy(), G[f"{tag}_dh2_both"], rtol=2e-4, atol=2e-7)
+    np.testing.assert_allclose(dh1b.numpy(), G[f"{tag}_dh1_both"], rtol=2e-4, atol=2e-7)
+    loss_nn, _, _, _ = _ntxent_hip(K, h1 * 0.1, h2 * 0.1, float(tau), normalize=False)
+    np.testing.assert_allclose(loss_nn.item(), G[f"{tag}_loss_nonorm"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ntxent_golden_multirank(K, golden_dir, world):
+    G = np.load(os.path.join(golden_dir, "ntxent_gloo.npz"))
+    torch.manual_seed(1234)
+    H1, H2 = torch.randn(world * 8, 128), torch.randn(world * 8, 128)
+    Z1, Z2 = O.l2_normalize(H1), O.l2_normalize(H2)
+    for r in range(world):
+        h1, h2 = H1[r * 8:(r + 1) * 8].contiguous(), H2[r * 8:(r + 1) * 8].contiguous()
+        loss, logits, dh2, _ = _ntxent_hip(K, h1, h2, 0.5, True, r, world, (Z1, Z2))
+        np.testing.assert_allclose(loss.item(), G[f"w{world}_loss"][r], rtol=2e-6)
+        np.testing.assert_allclose(logits.numpy(), G[f"w{world}_logits"][r], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(dh2.numpy(), G[f"w{world}_dh2"][r], rtol=2e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("b,n,tau", [(256, 256, 0.05), (512, 4096, 0.5), (100, 300, 0.1)])
+def test_ntxent_oracle_large(K, b, n, tau):
+    """BASELINE sizes (cfg2: B=N=256; cfg3: B=512, N=4096) and a ragged one against the oracle."""
+    g = torch.Generator().manual_seed(b + n)
+    world = n // b
+    H1, H2 = torch.randn(n, 128, generator=g), torch.randn(n, 128, generator=g)
+    Z1, Z2 = O.l2_normalize(H1), O.l2_normalize(H2)
+    rank = world - 1
+    h1, h2 = H1[rank * b:(rank + 1) * b].contiguous(), H2[rank * b:(rank + 1) * b].contiguous()
+    if world == 1:
+        ref_loss, ref_g = O.nt_xent_grad_h2(h1, h2, tau)
+        _, ref_logits, _ = O.nt_xent(h1, h2, tau)
+        loss, logits, dh2, _ = _ntxent_hip(K, h1, h2, tau)
+    else:
+        ref_loss, ref_g = O.nt_xent_grad_h2(h1, h2, tau, True, rank, world, (Z1, Z2))
+        _, ref_logits, _ = O.nt_xent(h1, h2, tau, True, rank, world, (Z1, Z2))
+        loss, logits, dh2, _ = _ntxent_hip(K, h1, h2, tau, True, rank, world, (Z1, Z2))
+    np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=5e-6)
+    np.testing.assert_allclose(logits.numpy(), ref_logits.numpy(), rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(dh2.numpy(), ref_g.numpy(), rtol=5e-4, atol=1e-7 + 1e-4 * ref_g.abs().max().item())
+
+
+# ---------------------------------------------------------------------------
+# layout, pooling, casts, optimiser, augmentation
+# ---------------------------------------------------------------------------
+def test_pack_views_bit_exact(K):
+    views = [torch.randint(0, 256, (5, 30, 30, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(k)) for k in range(4)]
+    ref = O.pack_views(views, 5, (30, 30))
+    for dtype in (torch.bfloat16, torch.float32):
+        out = K.pack_views_u8([v.cuda() for v in views], 32, dtype)
+        got = out.float().cpu()
+        assert torch.equal(got[..., :12].permute(0, 3, 1, 2), ref)
+        assert torch.count_nonzero(got[..., 12:]) == 0
+
+
+def test_stem_unroll_equals_7x7(K):
+    """7x1 conv over the kw-unrolled operand == the reference 7x7 stride-1 pad-3 stem."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randint(0, 256, (2, 3, 20, 18), generator=g).float()
+    w = rb(torch.randn(64, 3, 7, 7, generator=g) * 0.05)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 3)
+    wu = torch.zeros(64, 7, 1, 32)
+    for kw in range(7):
+        wu[:, :, 0, kw * 4:kw * 4 + 3] = w[:, :, :, kw].permute(0, 2, 1)
+    for src in (x.cuda(), x.permute(0, 2, 3, 1).contiguous().to(torch.uint8).cuda()):
+        xu = K.stem_unroll(src, torch.bfloat16)
+        y = K.conv2d(xu, wu.to(torch.bfloat16).cuda(), 1, 3, 0)
+        np.testing.assert_allclose(from_nhwc(y).numpy(), ref.float().numpy(), rtol=1 / 128, atol=0.5)
+
+
+def test_layout_roundtrip_and_pool(K):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 12, 9, 7, generator=g)
+    for dtype in (torch.bfloat16, torch.float32):
+        xn = K.nchw_to_nhwc(x.cuda(), 32, dtype)
+        back = K.nhwc_to_nchw(xn, 12).cpu()
+        assert torch.equal(back, rb(x) if dtype == torch.bfloat16 else x)
+        assert torch.count_nonzero(xn[..., 12:]) == 0
+    f = rb(torch.randn(2, 64, 28, 28, generator=g))
+    for dtype in (torch.bfloat16, torch.float32):
+        p = K.avgpool_fwd(nhwc(f, dtype), 4, 4)
+        np.testing.assert_allclose(from_nhwc(p).numpy(), F.adaptive_avg_pool2d(f, (4, 4)).numpy(), **tol(dtype))
+        dp = rb(torch.randn(2, 64, 4, 4, generator=g))
+        fd = f.clone().requires_grad_(True)
+        F.adaptive_avg_pool2d(fd, (4, 4)).backward(dp)
+        dx = K.avgpool_bwd(nhwc(dp, dtype), 28, 28)
+        np.testing.assert_allclose(from_nhwc(dx).numpy(), fd.grad.numpy(), rtol=1 / 128, atol=1e-4)
+
+
+def test_cast_roundtrip(K):
+    x = torch.randn(1000003, generator=torch.Generator().manual_seed(1))
+    x[5] = float("nan")
+    x[6] = float("inf")
+    b = K.cast_from_f32(x.cuda(), torch.bfloat16)
+    ref = x.to(torch.bfloat16)
+    assert torch.equal(b.cpu().view(torch.int16)[torch.isfinite(x)], ref.view(torch.int16)[torch.isfinite(x)])
+    assert torch.isnan(b.cpu()[5]) and torch.isinf(b.cpu()[6])
+    assert torch.equal(K.cast_to_f32(b).cpu()[7:], ref.float()[7:])
+
+
+def test_adam_matches_oracle(K):
+    g = torch.Generator().manual_seed(8)
+    p, gr = torch.randn(10007, generator=g), torch.randn(10007, generator=g)
+    m, v = torch.zeros(10007), torch.zeros(10007)
+    pg, mg, vg = p.cuda(), m.cuda(), v.cuda()
+    for step in range(1, 4):
+        gs = gr * step
+        p, m, v = O.adam_update(p, gs, m, v, step, 1e-3)
+        K.adam_step(pg, gs.cuda(), mg, vg, 1e-3, 0.9, 0.999, 1e-8, step)
+    np.testing.assert_allclose(pg.cpu().numpy(), p.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(vg.cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-9)
+    # torch.optim.SGD with momentum + weight decay
+    q = torch.nn.Parameter(torch.randn(501, generator=g))
+    opt = torch.optim.SGD([q], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    qg, mom = q.detach().clone().cuda(), torch.zeros(501, device="cuda")
+    for step in range(3):
+        q.grad = torch.randn(501, generator=g)
+        K.sgd_step(qg, q.grad.cuda(), mom, 0.1, 0.9, 1e-4, step == 0)
+        opt.step()
+    np.testing.assert_allclose(qg.cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_augment_bit_exact(K):
+    g = torch.Generator().manual_seed(12)
+    imgs = torch.randint(0, 256, (6, 64, 48, 3), dtype=torch.uint8, generator=g)
+    params = K.augment_params(6, 64, 48, seed=77, view=1, device="cuda")
+    pc = params.cpu()
+    assert (pc[:, 2] <= 48).all() and (pc[:, 3] <= 64).all() and (pc[:, 0] >= 0).all() and (pc[:, 0] + pc[:, 2] <= 48 + 1e-3).all()
+    assert ((pc[:, 4] == 0) | (pc[:, 4] == 1)).all()
+    area = pc[:, 2] * pc[:, 3] / (64 * 48)
+    assert (area > 0.05).all() and (area <= 1.0 + 1e-5).all()
+    out = K.augment_view_u8(imgs.cuda(), params, 32, 32).cpu()
+    for i in range(6):
+        ref = O.augment_view(imgs[i], pc[i], (32, 32))
+        assert torch.equal(out[i], ref), i
+    # different view id -> different parameters, same seed+view -> identical (counter-based)
+    p2 = K.augment_params(6, 64, 48, seed=77, view=2, device="cuda").cpu()
+    p1 = K.augment_params(6, 64, 48, seed=77, view=1, device="cuda").cpu()
+    assert torch.equal(p1, pc) and not torch.equal(p2, pc)
