@@ -1,0 +1,533 @@
+"""Execution engine of the SimCLR hot path on the HIP kernels.
+
+The reference runs ``g(f(x))`` through torch autograd over ~160 small modules
+(SimCLR.py:23-31, resnet.py:226-240, multilayerPerceptron.py:18-22).  Here the
+whole backbone (+ head) is ONE autograd node: the forward is an explicit
+sequence of conv(+BN statistics) / BN-apply launches on NHWC tensors and the
+backward is the hand-written reverse sequence (BN reduce -> BN apply -> weight
+gradient -> data gradient, residual gradients accumulated in the conv
+epilogue), so there is no per-op autograd bookkeeping, no NCHW<->NHWC traffic
+between layers and every saved tensor is explicit.
+
+Parameters stay ordinary fp32 ``nn.Parameter`` s in the reference layout
+(state_dict compatible); their bf16 / KHWC device copies are
+cached per optimiser step.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from ._lib import MaaiError
+
+_PRECISION = {"dtype": torch.bfloat16}
+_WEIGHT_EPOCH = [0]
+
+
+def set_precision(name):
+    """'bf16' (production: bf16 storage, fp32 MFMA accumulate) or 'fp32'
+    (fp32 storage + exact-fp32 MFMA: the parity mode)."""
+    if name not in ("bf16", "fp32"):
+        raise ValueError("precision must be 'bf16' or 'fp32'")
+    _PRECISION["dtype"] = torch.bfloat16 if name == "bf16" else torch.float32
+
+
+def get_precision():
+    return "bf16" if _PRECISION["dtype"] == torch.bfloat16 else "fp32"
+
+
+def compute_dtype():
+    return _PRECISION["dtype"]
+
+
+def bump_weight_epoch():
+    """Called by the HIP optimisers after they rewrite parameters through raw pointers."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+# ----------------------------------------------------------------------------
+# weight forms: reference layout (fp32) <-> kernel layout (storage dtype)
+# ----------------------------------------------------------------------------
+_CACHE = {}
+
+
+def _cached(param, tag, dtype, build):
+    key = (id(param), tag, dtype)
+    ver = (param._version, _WEIGHT_EPOCH[0], param.data_ptr())
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        t = build(param.detach())
+    _CACHE[key] = (ver, t)
+    return t
+
+
+def clear_weight_cache():
+    _CACHE.clear()
+
+
+def _cast(t, dtype):
+    t = t.contiguous()
+    return K.cast_from_f32(t, dtype) if dtype != torch.float32 else t
+
+
+def w_fwd(param, dtype, cin_pad=None):
+    """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin(_pad)]"""
+    def build(w):
+        w = w.permute(0, 2, 3, 1)
+        if cin_pad is not None and cin_pad != w.shape[3]:
+            w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[3]))
+        return _cast(w, dtype)
+    return _cached(param, ("fwd", cin_pad), dtype, build)
+
+
+def w_stem_unrolled(param, dtype):
+    """[64,3,7,7] -> [64,7,1,32] with channel kw*4+c (elementwise.hip stem_unroll)."""
+    def build(w):
+        co = w.shape[0]
+        wu = torch.zeros((co, 7, 8, 4), dtype=torch.float32, device=w.device)
+        wu[:, :, :7, :3] = w.permute(0, 2, 3, 1)  # [co, kh, kw, c]
+        return _cast(wu.reshape(co, 7, 1, 32), dtype)
+    return _cached(param, "stem_unrolled", dtype, build)
+
+
+def dgrad_classes(k, stride, pad):
+    """Per output-parity class a of the data gradient: (a, taps kh in ascending
+    input offset, pad') such that dx[s*h'+a] = sum_t dy[h' - pad' + t] * W[kh_t]."""
+    out = []
+    for a in range(stride):
+        taps = [(kh, (a + pad - kh) // stride) for kh in range(k) if (a + pad - kh) % stride == 0]
+        taps.sort(key=lambda t: t[1])
+        if taps:
+            offs = [o for _, o in taps]
+            assert offs == list(range(offs[0], offs[0] + len(offs)))
+            out.append((a, [kh for kh, _ in taps], -offs[0]))
+        else:
+            out.append((a, [], 0))
+    return out
+
+
+def w_dgrad(param, dtype, khs, kws):
+    """[Cout,Cin,KH,KW] -> [Cin,len(khs),len(kws),Cout] taking the listed taps in order."""
+    def build(w):
+        w = w[:, :, khs][:, :, :, kws]
+        return _cast(w.permute(1, 2, 3, 0), dtype)
+    return _cached(param, ("dgrad", tuple(khs), tuple(kws)), dtype, build)
+
+
+def w_linear(param, dtype, nhwc_from=None):
+    """[O,I] -> [O,1,1,I]; ``nhwc_from=(C,HW)`` permutes the input index from the
+    reference's NCHW flatten (c*HW+p, multilayerPerceptron.py:20) to NHWC (p*C+c)."""
+    def build(w):
+        o, i = w.shape
+        if nhwc_from is not None:
+            c, hw = nhwc_from
+            w = w.reshape(o, c, hw).permute(0, 2, 1).reshape(o, i)
+        return _cast(w.reshape(o, 1, 1, i), dtype)
+    return _cached(param, ("lin", nhwc_from), dtype, build)
+
+
+def w_linear_dgrad(param, dtype, nhwc_from=None):
+    """[O,I] -> [I,1,1,O]"""
+    def build(w):
+        o, i = w.shape
+        if nhwc_from is not None:
+            c, hw = nhwc_from
+            w = w.reshape(o, c, hw).permute(0, 2, 1).reshape(o, i)
+        return _cast(w.t().reshape(i, 1, 1, o), dtype)
+    return _cached(param, ("lin_dgrad", nhwc_from), dtype, build)
+
+
+# ----------------------------------------------------------------------------
+# conv + BN + act unit
+# ----------------------------------------------------------------------------
+class _Rec(object):
+    __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
+                 "count", "world", "training", "form", "in_hw")
+
+
+def _sync_world(bn):
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def _check_conv(conv):
+    if conv.groups != 1 or conv.dilation not in ((1, 1), 1):
+        raise MaaiError("HIP path supports groups=1, dilation=1 convolutions (got groups=%s dilation=%s)" % (conv.groups, conv.dilation))
+    if conv.bias is not None:
+        raise MaaiError("HIP path expects bias-free convolutions (resnet.py:22,28)")
+
+
+def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
+    """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None)."""
+    _check_conv(conv)
+    k = conv.kernel_size[0]
+    stride, pad = conv.stride[0], conv.padding[0]
+    if wq is None:
+        wq = w_fwd(conv.weight, dtype)
+    training = bn.training or (bn.running_mean is None)
+    kh, kw = wq.shape[1], wq.shape[2]
+    pad_w = pad if kw > 1 else 0
+    if training:
+        y, part = K.conv2d(x, wq, stride, pad, pad_w, stats=True)
+        c = y.shape[-1]
+        count = y.numel() // c
+        sums = K.reduce_partials(part)
+        world = _sync_world(bn)
+        if world > 1:
+            dist.all_reduce(sums)
+            count *= world
+        mom = bn.momentum
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked += 1
+            if mom is None:
+                mom = 1.0 / float(bn.num_batches_tracked)
+            rm, rv = bn.running_mean, bn.running_var
+        else:
+            rm = rv = None
+            mom = 0.0
+        mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
+    else:
+        y = K.conv2d(x, wq, stride, pad, pad_w)
+        scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        mean = invstd = None
+        count, world = y.numel() // y.shape[-1], 1
+    out = K.bn_act_fwd(y, scale, shift, residual, relu)
+    if not keep:
+        return out, None
+    r = _Rec()
+    r.x, r.y, r.out, r.conv, r.bn = x, y, out, conv, bn
+    r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
+    r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
+    r.in_hw = (x.shape[1], x.shape[2])
+    return out, r
+
+
+def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False):
+    """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]."""
+    n, cin = dy.shape[0], weight.shape[1]
+    ih, iw = in_hw
+    cls = dgrad_classes(k, stride, pad)
+    empty = any(len(c[1]) == 0 for c in cls)
+    if out is None:
+        alloc = torch.zeros if (empty and not accumulate) else torch.empty
+        out = alloc((n, ih, iw, cin), dtype=dy.dtype, device=dy.device)
+        if accumulate:
+            raise MaaiError("conv_dgrad: accumulate needs an output tensor")
+    for (a, khs, pad_h) in cls:
+        for (b, kws, pad_w) in cls:
+            if not khs or not kws:
+                continue
+            wq = w_dgrad(weight, dtype, khs, kws)
+            gh, gw = (ih - a + stride - 1) // stride, (iw - b + stride - 1) // stride
+            if gh <= 0 or gw <= 0:
+                continue
+            K.conv2d(dy, wq, 1, pad_h, pad_w, out=out, grid_hw=(gh, gw), out_hw=(ih, iw), out_stride=stride, out_off=(a, b),
+                     accumulate=accumulate)
+    return out
+
+
+def _grad_to_reference(rec, dw):
+    """kernel-layout fp32 weight gradient -> reference [Cout,Cin,KH,KW]"""
+    w = rec.conv.weight
+    if rec.form == "stem_unrolled":
+        co = dw.shape[0]
+        return dw.reshape(co, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
+    g = dw.permute(0, 3, 1, 2)
+    if g.shape[1] != w.shape[1]:
+        g = g[:, :w.shape[1]]
+    return g.contiguous()
+
+
+def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False):
+    """Backward of unit_fwd.  Returns (dx or None, dz or None); parameter gradients go to ``grads``."""
+    bn = rec.bn
+    if rec.training:
+        sums = K.bn_act_bwd_reduce(dout, rec.out if rec.relu else None, rec.y, rec.mean, rec.relu)
+        gamma = bn.weight
+        if rec.world > 1:
+            # torch SyncBatchNorm: weight/bias gradients from the LOCAL sums, dx from the all-reduced ones
+            dgamma, dbeta, _, _, _ = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
+            dist.all_reduce(sums)
+            _, _, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
+        else:
+            dgamma, dbeta, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
+    else:
+        # frozen statistics: y -> y*scale + shift is a per-channel affine map
+        sums = K.bn_act_bwd_reduce(dout, rec.out if rec.relu else None, rec.y, bn.running_mean, rec.relu)
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        dbeta = sums[:sums.numel() // 2].float()
+        dgamma = (sums[sums.numel() // 2:].float() * invstd)
+        k1, k2, k3 = rec.scale, torch.zeros_like(rec.scale), torch.zeros_like(rec.scale)
+    if bn.weight is not None and bn.weight.requires_grad:
+        grads[id(bn.weight)] = dgamma
+    if bn.bias is not None and bn.bias.requires_grad:
+        grads[id(bn.bias)] = dbeta
+    dy, dz = K.bn_act_bwd_apply(dout, rec.out if rec.relu else None, rec.y, k1, k2, k3, rec.relu, True, rec.has_res)
+    w = rec.conv.weight
+    if w.requires_grad:
+        kh = 7 if rec.form == "stem_unrolled" else rec.k
+        kw = 1 if rec.form == "stem_unrolled" else rec.k
+        pw = 0 if rec.form == "stem_unrolled" else rec.pad
+        dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
+        grads[id(w)] = _grad_to_reference(rec, dw)
+    dx = None
+    if need_dx:
+        dx = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate)
+    return dx, dz
+
+
+# ----------------------------------------------------------------------------
+# backbone
+# ----------------------------------------------------------------------------
+def _blocks(resnet):
+    for name in ("layer1", "layer2", "layer3", "layer4"):
+        for blk in getattr(resnet, name):
+            yield blk
+
+
+def stem_input(x, conv1, dtype):
+    """NCHW fp32 / list of u8 HWC views -> (stem operand NHWC, weights, form)."""
+    cin = conv1.weight.shape[1]
+    if isinstance(x, (list, tuple)):
+        if cin != 3 * len(x):
+            raise MaaiError("stem: %d views do not match conv1 with %d input channels" % (len(x), cin))
+        if cin == 3:
+            return K.stem_unroll(x[0], dtype), w_stem_unrolled(conv1.weight, dtype), "stem_unrolled"
+        cpad = (cin + 31) // 32 * 32
+        return K.pack_views_u8(list(x), cpad, dtype), w_fwd(conv1.weight, dtype, cpad), "fwd"
+    if x.dim() != 4 or x.shape[1] != cin:
+        raise MaaiError("stem: expected NCHW input with %d channels, got %s" % (cin, tuple(x.shape)))
+    x = x.contiguous().float()
+    if cin == 3 and conv1.kernel_size == (7, 7) and conv1.stride == (1, 1) and conv1.padding == (3, 3):
+        return K.stem_unroll(x, dtype), w_stem_unrolled(conv1.weight, dtype), "stem_unrolled"
+    cpad = (cin + 31) // 32 * 32
+    return K.nchw_to_nhwc(x, cpad, dtype), w_fwd(conv1.weight, dtype, cpad), "fwd"
+
+
+def backbone_fwd(resnet, x, dtype, keep):
+    """resnet.py:226-240.  Returns (NHWC feature map, tape)."""
+    xs, wq, form = stem_input(x, resnet.conv1, dtype)
+    tape = []
+    out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form)
+    tape.append(("stem", r))
+    for blk in _blocks(resnet):
+        xin = out
+        if hasattr(blk, "conv3"):  # Bottleneck (resnet.py:113-135)
+            o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep)
+            o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep)
+            last_conv, last_bn = blk.conv3, blk.bn3
+        else:  # BasicBlock (resnet.py:59-77)
+            o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep)
+            r2 = None
+            last_conv, last_bn = blk.conv2, blk.bn2
+        rd = None
+        if blk.downsample is not None:
+            idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep)
+        else:
+            idn = xin
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep)
+        tape.append(("block", r1, r2, r3, rd))
+    return out, tape
+
+
+def block_bwd(entry, dout, grads, dtype):
+    """Backward of one residual block; returns the gradient wrt the block input."""
+    _, r1, r2, r3, rd = entry
+    d, dz = unit_bwd(r3, dout, grads, dtype)           # d: grad wrt the last conv's input, dz: grad wrt identity
+    if r2 is not None:
+        d, _ = unit_bwd(r2, d, grads, dtype)
+    if rd is not None:
+        # dx = dgrad(conv1) (dense) then += dgrad(downsample) (strided scatter, accumulate epilogue)
+        dx, _ = unit_bwd(r1, d, grads, dtype)
+        unit_bwd(rd, dz, grads, dtype, dx_out=dx, accumulate=True)
+    else:
+        # identity shortcut: dx = dz + dgrad(conv1), accumulated in the conv epilogue
+        dx, _ = unit_bwd(r1, d, grads, dtype, dx_out=dz, accumulate=True)
+    return dx
+
+
+def backbone_bwd(tape, dout, grads, dtype):
+    for entry in reversed(tape):
+        if entry[0] == "stem":
+            unit_bwd(entry[1], dout, grads, dtype, need_dx=False)
+            return
+        dout = block_bwd(entry, dout, grads, dtype)
+
+
+# ----------------------------------------------------------------------------
+# head (multilayerPerceptron.py:9-22) on NHWC features
+# ----------------------------------------------------------------------------
+def _check_mlp(mlp):
+    l0, l2 = mlp.layers[0], mlp.layers[2]
+    if l0.in_features % 32 or l0.out_features % 64 or l2.out_features % 64 or l2.in_features % 32:
+        raise MaaiError("HIP MLP needs in %% 32 == 0 and hidden/out %% 64 == 0 (got %d,%d,%d)" %
+                        (l0.in_features, l0.out_features, l2.out_features))
+    return l0, l2
+
+
+def head_fwd(mlp, feat, dtype, keep, pool=None, nhwc=True):
+    """feat: NHWC [B,h,w,C] (nhwc=True, W1 columns permuted on the fly) or an
+    already NCHW-flattened [B,1,1,D] tensor (nhwc=False)."""
+    l0, l2 = _check_mlp(mlp)
+    b = feat.shape[0]
+    pooled_from = None
+    if nhwc:
+        h, w, c = feat.shape[1:]
+        if pool is not None and (h != pool or w != pool):
+            pooled_from = (h, w)
+            feat = K.avgpool_fwd(feat, pool, pool)
+            h = w = pool
+        if h * w * c != l0.in_features:
+            raise MaaiError("MLP expects %d input features, backbone gives %d x %d x %d" % (l0.in_features, c, h, w))
+        v = feat.reshape(b, 1, 1, h * w * c)
+        perm = (c, h * w)
+    else:
+        v, perm = feat, None
+    y1 = K.conv2d(v, w_linear(l0.weight, dtype, perm), 1, 0, 0)
+    hdn = K.bn_act_fwd(y1, None, l0.bias, None, True)
+    h32 = K.cast_to_f32(hdn)
+    y2 = K.conv2d(h32, w_linear(l2.weight, torch.float32), 1, 0, 0)
+    z = K.bn_act_fwd(y2, None, l2.bias, None, False).reshape(b, l2.out_features)
+    tape = (v, hdn, h32, perm, pooled_from, feat.shape) if keep else None
+    return z, tape
+
+
+def head_bwd(mlp, tape, dz, grads, dtype, need_dfeat=True):
+    l0, l2 = mlp.layers[0], mlp.layers[2]
+    v, hdn, h32, perm, pooled_from, fshape = tape
+    b = dz.shape[0]
+    dz4 = dz.contiguous().float().reshape(b, 1, 1, l2.out_features)
+    if l2.bias is not None and l2.bias.requires_grad:
+        grads[id(l2.bias)] = K.bn_act_bwd_reduce(dz4, None, None, None, False)[:l2.out_features].float()
+    if l2.weight.requires_grad:
+        grads[id(l2.weight)] = K.conv2d_wgrad(h32, dz4, 1, 1).reshape(l2.out_features, l2.in_features)
+    dh32 = K.conv2d(dz4, w_linear_dgrad(l2.weight, torch.float32), 1, 0, 0)
+    dh = K.cast_from_f32(dh32, dtype)
+    dy1, _ = K.bn_act_bwd_apply(dh, hdn, None, None, None, None, True, True, False)
+    if l0.bias is not None and l0.bias.requires_grad:
+        grads[id(l0.bias)] = K.bn_act_bwd_reduce(dy1, None, None, None, False)[:l0.out_features].float()
+    if l0.weight.requires_grad:
+        dw = K.conv2d_wgrad(v, dy1, 1, 1).reshape(l0.out_features, l0.in_features)
+        if perm is not None:
+            c, hw = perm
+            dw = dw.reshape(l0.out_features, hw, c).permute(0, 2, 1).reshape(l0.out_features, l0.in_features).contiguous()
+        grads[id(l0.weight)] = dw
+    if not need_dfeat:
+        return None
+    dv = K.conv2d(dy1, w_linear_dgrad(l0.weight, dtype, perm), 1, 0, 0)
+    if perm is None:
+        return dv
+    dfeat = dv.reshape(fshape)
+    if pooled_from is not None:
+        dfeat = K.avgpool_bwd(dfeat, pooled_from[0], pooled_from[1])
+    return dfeat
+
+
+# ----------------------------------------------------------------------------
+# autograd nodes
+# ----------------------------------------------------------------------------
+def trainable_params(*modules):
+    seen, out = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+def _need_gpu_module(m):
+    p = next(m.parameters(), None)
+    if p is not None and not p.is_cuda:
+        raise MaaiError("the HIP path needs the module on a HIP device (got %s); there is no CPU fallback — "
+                        "call .to('cuda') first" % p.device)
+
+
+class _FusedFn(torch.autograd.Function):
+    """z = g(pool(f(x))) entirely in NHWC (SimCLR.py:25-29)."""
+
+    @staticmethod
+    def forward(ctx, x, f, g, pool, keep, *params):
+        dtype = compute_dtype()
+        feat, tape = backbone_fwd(f, x, dtype, keep)
+        z, htape = head_fwd(g, feat, dtype, keep, pool, nhwc=True)
+        ctx.f, ctx.g, ctx.tape, ctx.htape, ctx.dtype, ctx.params = f, g, tape, htape, dtype, params
+        ctx.keep = keep
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if not ctx.keep:
+            raise MaaiError("backward through a forward that ran without gradients")
+        grads = {}
+        dfeat = head_bwd(ctx.g, ctx.htape, dz, grads, ctx.dtype)
+        backbone_bwd(ctx.tape, dfeat, grads, ctx.dtype)
+        ctx.tape = ctx.htape = None
+        return (None, None, None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """f(x): NCHW fp32 in, NCHW fp32 out — the reference's ResNet.forward contract."""
+
+    @staticmethod
+    def forward(ctx, x, f, keep, *params):
+        dtype = compute_dtype()
+        feat, tape = backbone_fwd(f, x, dtype, keep)
+        ctx.tape, ctx.dtype, ctx.params, ctx.keep, ctx.cpad = tape, dtype, params, keep, feat.shape[-1]
+        return K.nhwc_to_nchw(feat, feat.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        if not ctx.keep:
+            raise MaaiError("backward through a forward that ran without gradients")
+        grads = {}
+        d = K.nchw_to_nhwc(dfeat.contiguous().float(), ctx.cpad, ctx.dtype)
+        backbone_bwd(ctx.tape, d, grads, ctx.dtype)
+        ctx.tape = None
+        return (None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+
+
+class _HeadFn(torch.autograd.Function):
+    """g(v): [B, ...] fp32 flattened in the caller's (NCHW) order."""
+
+    @staticmethod
+    def forward(ctx, v, g, keep, *params):
+        dtype = compute_dtype()
+        b = v.shape[0]
+        flat = v.reshape(b, -1).contiguous().float()
+        vin = K.cast_from_f32(flat, dtype).reshape(b, 1, 1, flat.shape[1])
+        z, tape = head_fwd(g, vin, dtype, keep, None, nhwc=False)
+        ctx.g, ctx.tape, ctx.dtype, ctx.params, ctx.keep, ctx.vshape, ctx.need_dv = g, tape, dtype, params, keep, v.shape, v.requires_grad
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        grads = {}
+        dv = head_bwd(ctx.g, ctx.tape, dz, grads, ctx.dtype, need_dfeat=ctx.need_dv)
+        ctx.tape = None
+        if dv is not None:
+            dv = K.cast_to_f32(dv).reshape(ctx.vshape)
+        return (dv, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+
+
+def fused_forward(f, g, x, pool=None):
+    _need_gpu_module(f)
+    params = trainable_params(f, g)
+    keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _FusedFn.apply(x, f, g, pool, keep, *params)
+
+
+def backbone_forward(f, x):
+    _need_gpu_module(f)
+    params = trainable_params(f)
+    keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _BackboneFn.apply(x, f, keep, *params)
+
+
+def head_forward(g, v):
+    _need_gpu_module(g)
+    params = trainable_params(g)
+    keep = torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params))
+    return _HeadFn.apply(v, g, keep, *params)

@@ -1,0 +1,119 @@
+"""Optimisers of the path (Model_Util.py:68-88) on the fused HIP update kernels.
+torch.optim.Optimizer subclasses so that param_groups / state / state_dict /
+``optimizer.state[p]['step']`` (read by learning_rate_schedule, Model_Util.py:11-15)
+behave like torch.optim.Adam / SGD."""
+import torch
+
+from . import kernels as K
+from .engine import bump_weight_epoch
+
+
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr) semantics (no weight decay / amsgrad: the reference uses neither)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                K.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+        bump_weight_epoch()
+        return loss
+
+
+class HipSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(params, lr, momentum, weight_decay) semantics (dampening 0, no nesterov)."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                    st["step"] = 0
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                K.sgd_step(p, g, st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"], first)
+        bump_weight_epoch()
+        return loss
+
+
+class LARC(object):
+    """Layer-wise adaptive rate clipping around another optimiser, following
+    Apex's published algorithm (apex/parallel/LARC.py: trust_coefficient 0.02,
+    clip=True, eps 1e-8): each gradient is scaled by
+    min(trust*||w||/(||g|| + wd*||w|| + eps) / lr, 1) before the wrapped step.
+    Apex is not installable offline, so parity of this class is UNPINNED
+    (SURVEY §8c); it exists so that ``--optimizer lars`` (Model_Util.py:80-83,
+    = LARC(Adam)) keeps working."""
+
+    def __init__(self, optimizer, trust_coefficient=0.02, clip=True, eps=1e-8):
+        self.optim, self.trust_coefficient, self.clip, self.eps = optimizer, trust_coefficient, clip, eps
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["optim"], name)
+
+    @property
+    def state(self):
+        return self.optim.state
+
+    @property
+    def param_groups(self):
+        return self.optim.param_groups
+
+    def state_dict(self):
+        return self.optim.state_dict()
+
+    def load_state_dict(self, sd):
+        self.optim.load_state_dict(sd)
+
+    def zero_grad(self, *a, **k):
+        self.optim.zero_grad(*a, **k)
+
+    def step(self):
+        with torch.no_grad():
+            saved = []
+            for group in self.optim.param_groups:
+                wd = group.get("weight_decay", 0.0)
+                saved.append(wd)
+                group["weight_decay"] = 0.0
+                for p in group["params"]:
+                    if p.grad is None:
+                        continue
+                    pn, gn = torch.norm(p), torch.norm(p.grad)
+                    rate = self.trust_coefficient * pn / (gn + pn * wd + self.eps)
+                    if self.clip:
+                        rate = torch.clamp(rate / group["lr"], max=1.0)
+                    rate = torch.where((pn > 0) & (gn > 0), rate, torch.ones_like(rate))
+                    p.grad.add_(p, alpha=wd)
+                    p.grad.mul_(rate)
+        self.optim.step()
+        for group, wd in zip(self.optim.param_groups, saved):
+            group["weight_decay"] = wd

@@ -221,36 +221,45 @@ def _conv(x, w, stride, pad, storage):
     return _rnd(y32, storage), y32
 
 
+def stem_forward(sd, x, training=True, storage="fp32", new_stats=None):
+    """resnet.py:228-230: conv1 (7x7, stride 1, pad 3) -> bn1 -> relu; max-pool NOT applied (:231)."""
+    y, y32 = _conv(_rnd(x, storage), sd["f.conv1.weight"], 1, 3, storage)
+    return _rnd(F.relu(batch_norm(y, sd, "f.bn1", training, new_stats, storage, y32)), storage)
+
+
+def block_forward(sd, x, blk, training=True, storage="fp32", new_stats=None):
+    """One residual block (BasicBlock resnet.py:59-77 / Bottleneck resnet.py:113-135, v1.5: stride on the 3x3)."""
+    p = blk["prefix"]
+    identity = x
+    if blk["kind"] == "basic":
+        y, y32 = _conv(x, sd[p + ".conv1.weight"], blk["stride"], 1, storage)
+        o = _rnd(F.relu(batch_norm(y, sd, p + ".bn1", training, new_stats, storage, y32)), storage)
+        y, y32 = _conv(o, sd[p + ".conv2.weight"], 1, 1, storage)
+        o = batch_norm(y, sd, p + ".bn2", training, new_stats, storage, y32)
+    else:
+        y, y32 = _conv(x, sd[p + ".conv1.weight"], 1, 0, storage)
+        o = _rnd(F.relu(batch_norm(y, sd, p + ".bn1", training, new_stats, storage, y32)), storage)
+        y, y32 = _conv(o, sd[p + ".conv2.weight"], blk["stride"], 1, storage)
+        o = _rnd(F.relu(batch_norm(y, sd, p + ".bn2", training, new_stats, storage, y32)), storage)
+        y, y32 = _conv(o, sd[p + ".conv3.weight"], 1, 0, storage)
+        o = batch_norm(y, sd, p + ".bn3", training, new_stats, storage, y32)
+    if blk["downsample"]:
+        y, y32 = _conv(x, sd[p + ".downsample.0.weight"], blk["stride"], 0, storage)
+        identity = batch_norm(y, sd, p + ".downsample.1", training, new_stats, storage, y32)
+    return _rnd(F.relu(o + identity), storage)
+
+
 def backbone_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, arch: str, training: bool = True,
                      storage: str = "fp32", new_stats: Optional[dict] = None,
                      taps: Optional[dict] = None) -> torch.Tensor:
     """resnet.py:226-240: conv1 -> bn1 -> relu -> layer1..4; no maxpool/avgpool/fc."""
-    x = _rnd(x, storage)
-    y, y32 = _conv(x, sd["f.conv1.weight"], 1, 3, storage)
-    x = _rnd(F.relu(batch_norm(y, sd, "f.bn1", training, new_stats, storage, y32)), storage)
+    x = stem_forward(sd, x, training, storage, new_stats)
     if taps is not None:
         taps["stem"] = x
     for blk in block_plan(arch):
-        p = blk["prefix"]
-        identity = x
-        if blk["kind"] == "basic":  # resnet.py:59-77
-            y, y32 = _conv(x, sd[p + ".conv1.weight"], blk["stride"], 1, storage)
-            o = _rnd(F.relu(batch_norm(y, sd, p + ".bn1", training, new_stats, storage, y32)), storage)
-            y, y32 = _conv(o, sd[p + ".conv2.weight"], 1, 1, storage)
-            o = batch_norm(y, sd, p + ".bn2", training, new_stats, storage, y32)
-        else:  # resnet.py:113-135 (v1.5: stride on the 3x3)
-            y, y32 = _conv(x, sd[p + ".conv1.weight"], 1, 0, storage)
-            o = _rnd(F.relu(batch_norm(y, sd, p + ".bn1", training, new_stats, storage, y32)), storage)
-            y, y32 = _conv(o, sd[p + ".conv2.weight"], blk["stride"], 1, storage)
-            o = _rnd(F.relu(batch_norm(y, sd, p + ".bn2", training, new_stats, storage, y32)), storage)
-            y, y32 = _conv(o, sd[p + ".conv3.weight"], 1, 0, storage)
-            o = batch_norm(y, sd, p + ".bn3", training, new_stats, storage, y32)
-        if blk["downsample"]:
-            y, y32 = _conv(x, sd[p + ".downsample.0.weight"], blk["stride"], 0, storage)
-            identity = batch_norm(y, sd, p + ".downsample.1", training, new_stats, storage, y32)
-        x = _rnd(F.relu(o + identity), storage)
+        x = block_forward(sd, x, blk, training, storage, new_stats)
         if taps is not None:
-            taps[p] = x
+            taps[blk["prefix"]] = x
     return x
 
 
@@ -264,7 +273,8 @@ def head_forward(sd: Dict[str, torch.Tensor], feat: torch.Tensor, storage: str =
     v = feat.reshape(feat.shape[0], -1)
     h = F.linear(v, _rnd(sd["g.layers.0.weight"], storage), sd["g.layers.0.bias"])
     h = _rnd(F.relu(h), storage)
-    return F.linear(h, _rnd(sd["g.layers.2.weight"], storage), sd["g.layers.2.bias"])
+    # the last GEMM runs in exact fp32 on the HIP path (fp32 weights, fp32 output)
+    return F.linear(h, sd["g.layers.2.weight"], sd["g.layers.2.bias"])
 
 
 def simclr_forward(sd, x, arch, training=True, storage="fp32", new_stats=None, pool=None, taps=None):

@@ -117,7 +117,7 @@ if __name__ == "__main__":
     B = 16
     x1 = inputs_uniform_u8(100, (B, 3, 32, 32)).float()
     x2 = inputs_uniform_u8(101, (B, 3, 32, 32)).float()
-    m = build_ref("resnet18", 1, 512 * 16, B, (32, 32)); m.train()
+    m = build_ref("resnet18", 1, 512 * 16, B, (32, 32), 0.25); m.train()
     opt = torch.optim.Adam(m.parameters(), 1e-3)
     traj, first = [], {}
     with torch.no_grad():

@@ -60,7 +60,7 @@ def test_resnet18_cfg1_step(golden_dir):
     B = 16
     x1 = _u8(100, (B, 3, 32, 32)).float()
     x2 = _u8(101, (B, 3, 32, 32)).float()
-    sd = O.pattern_state_dict("resnet18", 1, 512 * 16)
+    sd = O.pattern_state_dict("resnet18", 1, 512 * 16, residual_gamma=0.25)
     opt = {}
     traj = []
     h1 = None
