@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""SimCLR ResNet-50 training-step benchmark on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one per-GPU batch of synthetic source
+images already resident in HBM (reference --num-fixations 1
+semantics, Contrastive_Learning.py:638-700): two-view HIP augmentation ->
+view-1 forward (no grad, train-mode BN) -> view-2 forward -> NT-Xent (h1
+detached; embedding all-gather when N > 1) -> backward -> (gradient all-reduce
+when N > 1) -> Adam.  Workload at every N: BASELINE configs[1] per GPU —
+ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224, per-GPU
+batch 256, bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,
+1024,128), temperature 0.5 — i.e. weak scaling.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multimodal-active-ai_amd")
+SIM = os.path.join(PKG, "SimCLR")
+for d in (ROOT, PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP")):
+    if d not in sys.path:
+        sys.path.insert(0, d)
+
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): dense bf16 MFMA, HBM3E
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE cfg2: 256)")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--arch", default="resnet50")
+    ap.add_argument("--temperature", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
+    ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
+    return ap.parse_args()
+
+
+def build(args, device, world):
+    import resnet as rn
+    import multilayerPerceptron as mlp
+    import SimCLR
+    import Model_Util
+    norm = torch.nn.SyncBatchNorm if world > 1 else torch.nn.BatchNorm2d  # the drivers always pass SyncBatchNorm (Contrastive_Learning.py:240-252)
+    torch.manual_seed(1234)  # identical random-init weights on every rank (stands in for DDP's constructor broadcast)
+    f = getattr(rn, args.arch)(crop_measures=1, norm_layer=norm)
+    exp = 4 if hasattr(f.layer1[0], "conv3") else 1
+    g = mlp.MLP(512 * exp * 16, 1024, 128)
+    model = SimCLR.SimCLR_Module(f, g, args.batch, (args.img, args.img), device).to(device)
+    model.head_pool = 4
+    model.train()
+
+    class A:
+        optimizer, lr, momentum, weight_decay = "adam", 1e-3, 0.9, 0.0
+    return model, Model_Util.get_optimizer(model, A)
+
+
+def make_step(args, model, opt, device, rank, world):
+    import Objective
+    from maai_hip import kernels as K
+    from maai_hip.dist import GradAllReduce
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    images = torch.randint(0, 256, (args.batch, args.img, args.img, 3), dtype=torch.uint8, device=device, generator=gen)
+    sync = GradAllReduce(list(model.parameters())) if world > 1 else None
+    state = {"it": 0}
+
+    def step():
+        it = state["it"]
+        state["it"] += 1
+        p1 = K.augment_params(args.batch, args.img, args.img, seed=1000 + rank, view=2 * it, device=device)
+        p2 = K.augment_params(args.batch, args.img, args.img, seed=1000 + rank, view=2 * it + 1, device=device)
+        v1 = K.augment_view_u8(images, p1, args.img, args.img)
+        v2 = K.augment_view_u8(images, p2, args.img, args.img)
+        with torch.no_grad():
+            h1 = model([v1])
+        h2 = model([v2])
+        loss, _, _ = Objective.contrastive_loss(hidden1=h1.data, hidden2=h2, temperature=args.temperature,
+                                                local_rank=rank, world_size=world, device=device)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if sync is not None:
+            sync()
+        opt.step()
+        return loss
+    return step
+
+
+def cpu_baseline(args):
+    """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload."""
+    from oracle import simclr_oracle as O
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    b = args.cpu_batch
+    exp = O.expansion(args.arch)
+    sd = O.pattern_state_dict(args.arch, 1, 512 * exp * 16)
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
+    x2 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
+    opt = {}
+    O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)  # warm-up
+    t0 = time.time()
+    for _ in range(args.cpu_steps):
+        O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)
+    dt = (time.time() - t0) / args.cpu_steps
+    return dict(value=round(b / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="%s 3x%dx%d, batch %d, %d steps (fp32, torch-CPU oracle)" % (args.arch, args.img, args.img, b, args.cpu_steps))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    model, opt = build(args, device, world)
+    step = make_step(args, model, opt, device, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    # one extra, untimed, instrumented step: per-kernel HIP-event durations on the launch stream
+    from maai_hip import kernels as K
+    with K.profile() as prof:
+        step()
+    table = prof.table()
+    if args.detail:
+        K.DETAIL[0] = True
+        with K.profile() as prof2:
+            step()
+        K.DETAIL[0] = False
+        detail = prof2.table()
+        if rank == 0 and args.profile_table:
+            with open(args.profile_table + ".detail", "w") as fh:
+                json.dump(detail, fh, indent=1)
+    roof = None
+    if table:
+        dom = max(table, key=lambda k: table[k]["ms"])
+        t = table[dom]
+        if t["flops"] > 0:
+            ach = t["flops"] / (t["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches=t["launches"],
+                        avg_launch_ms=round(t["ms"] / t["launches"], 4), share_of_step=round(t["ms"] / ms, 3))
+        else:
+            ach = t["bytes"] / (t["ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, launches=t["launches"],
+                        avg_launch_ms=round(t["ms"] / t["launches"], 4), share_of_step=round(t["ms"] / ms, 3))
+    if rank == 0 and args.profile_table:
+        with open(args.profile_table, "w") as fh:
+            json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in table.items()}, fh, indent=1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec SimCLR ResNet-50 224px, global batch 4096, 1/2/4/8 MI355X",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SimCLR %s 3x%dx%d (reference stem), per-GPU batch %d, two-view step: aug + fwd(view1, no grad) + "
+                                   "fwd(view2) + NT-Xent tau=%g + bwd + Adam" % (args.arch, args.img, args.img, args.batch, args.temperature),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.item())},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

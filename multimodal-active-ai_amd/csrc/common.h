@@ -16,8 +16,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 extern "C" void maai_set_error(const char* msg);
 
+// also clears any stale (sticky) runtime error so that MAAI_CHECK_LAUNCH reports only our own launch
 #define MAAI_CHECK_ARG(cond, msg)        \
   do {                                   \
+    (void)hipGetLastError();             \
     if (!(cond)) {                       \
       maai_set_error(msg);               \
       return MAAI_ERR_ARG;               \

@@ -7,6 +7,8 @@ if the tensors are not on a HIP device.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must come first: libmaai_hip.so has to bind to the HIP runtime torch already loaded)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmaai_hip.so")

@@ -310,7 +310,10 @@ def backbone_fwd(resnet, x, dtype, keep):
     """resnet.py:226-240.  Returns (NHWC feature map, tape)."""
     xs, wq, form = stem_input(x, resnet.conv1, dtype)
     tape = []
+    cin = resnet.conv1.weight.shape[1]
+    K.FLOPS_SCALE[0] = (49.0 * cin) / (wq.shape[1] * wq.shape[2] * wq.shape[3])  # executed K includes zero padding
     out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form)
+    K.FLOPS_SCALE[0] = 1.0
     tape.append(("stem", r))
     for blk in _blocks(resnet):
         xin = out
@@ -351,7 +354,10 @@ def block_bwd(entry, dout, grads, dtype):
 def backbone_bwd(tape, dout, grads, dtype):
     for entry in reversed(tape):
         if entry[0] == "stem":
-            unit_bwd(entry[1], dout, grads, dtype, need_dx=False)
+            r = entry[1]
+            K.FLOPS_SCALE[0] = (49.0 * r.conv.weight.shape[1]) / ((7 if r.form == "stem_unrolled" else 49) * r.x.shape[-1])
+            unit_bwd(r, dout, grads, dtype, need_dx=False)
+            K.FLOPS_SCALE[0] = 1.0
             return
         dout = block_bwd(entry, dout, grads, dtype)
 

@@ -37,6 +37,58 @@ def _stream():
 
 
 # ----------------------------------------------------------------------------
+# optional per-launch timing (HIP events on the launch stream) for bench.py's
+# roofline: records (kernel, algorithmic flops, algorithmic bytes, start, end)
+# ----------------------------------------------------------------------------
+_PROF = None
+DETAIL = [False]  # True: conv records carry their geometry in the name
+FLOPS_SCALE = [1.0]  # set by the engine around the stem (executed K includes zero padding)
+
+
+class profile(object):
+    """with kernels.profile() as prof: ... ; prof.table() -> {kernel: dict(ms, flops, bytes, launches)}"""
+
+    def __enter__(self):
+        global _PROF
+        self.records = []
+        _PROF = self.records
+        return self
+
+    def __exit__(self, *a):
+        global _PROF
+        _PROF = None
+        torch.cuda.synchronize()
+
+    def table(self):
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            t = out.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            t["ms"] += e0.elapsed_time(e1)
+            t["flops"] += flops
+            t["bytes"] += nbytes
+            t["launches"] += 1
+        return out
+
+
+class _timed(object):
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if _PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROF.append((self.name, self.flops, self.bytes, self.e0, e1))
+
+
+# ----------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------
 def conv_out_hw(ih, iw, kh, kw, stride, pad_h, pad_w):
@@ -69,7 +121,12 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     if stats:
         rows = lib().maai_conv2d_stats_rows(C.byref(d))
         part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
-    check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _dt(x), _stream()), "maai_conv2d_igemm")
+    m = d.N * d.OHg * d.OWg
+    es = x.element_size()
+    nm = "conv_igemm" if not DETAIL[0] else "conv_igemm M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
+                es * (x.numel() + w.numel() + m * d.Cout * (2 if accumulate else 1))):
+        check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _dt(x), _stream()), "maai_conv2d_igemm")
     return (out, part) if stats else out
 
 
@@ -80,7 +137,9 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
     _, oh, ow, cout = dy.shape
     d = ConvDesc(n, ih, iw, cin, cout, kh, kw, stride, pad_h, pad_w, oh, ow, oh, ow, 1, 0, 0, 0)
     dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
-    check(lib().maai_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), _stream()), "maai_conv2d_wgrad")
+    nm = "conv_wgrad" if not DETAIL[0] else "conv_wgrad M%d Cin%d Cout%d k%dx%d s%d" % (dy.numel() // cout, cin, cout, kh, kw, stride)
+    with _timed(nm, 2.0 * dy.numel() * kh * kw * cin * FLOPS_SCALE[0], x.element_size() * (x.numel() + dy.numel()) + 4 * dw.numel()):
+        check(lib().maai_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), _stream()), "maai_conv2d_wgrad")
     return dw
 
 
@@ -93,7 +152,8 @@ def reduce_partials(partial):
     rows = partial.shape[0]
     c2 = partial.numel() // rows
     sums = torch.empty(c2, dtype=torch.float64, device=partial.device)
-    check(lib().maai_reduce_partials(_p(partial), rows, c2, _p(sums), _stream()), "maai_reduce_partials")
+    with _timed("reduce_partials", 0.0, 4.0 * partial.numel()):
+        check(lib().maai_reduce_partials(_p(partial), rows, c2, _p(sums), _stream()), "maai_reduce_partials")
     return sums
 
 
@@ -122,8 +182,9 @@ def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None):
     m = y.numel() // c
     if out is None:
         out = torch.empty_like(y)
-    check(lib().maai_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(residual), _p(out), m, c, 1 if relu else 0, _dt(y), _stream()),
-          "maai_bn_act_fwd")
+    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * (3 if residual is not None else 2)):
+        check(lib().maai_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(residual), _p(out), m, c, 1 if relu else 0, _dt(y), _stream()),
+              "maai_bn_act_fwd")
     return out
 
 
@@ -136,8 +197,10 @@ def bn_act_bwd_reduce(dout, out, y, mean, relu):
     part = torch.empty((rows, 2, c), dtype=torch.float32, device=dout.device)
     if y is None:
         part.zero_()
-    check(lib().maai_bn_act_bwd_reduce(_p(dout), _p(out), _p(y), _p(mean), _p(part), m, c, 1 if relu else 0, _dt(dout),
-                                       _stream()), "maai_bn_act_bwd_reduce")
+    nt = 1 + (1 if relu else 0) + (1 if y is not None else 0)
+    with _timed("bn_bwd_reduce", 0.0, dout.element_size() * dout.numel() * nt):
+        check(lib().maai_bn_act_bwd_reduce(_p(dout), _p(out), _p(y), _p(mean), _p(part), m, c, 1 if relu else 0, _dt(dout),
+                                           _stream()), "maai_bn_act_bwd_reduce")
     return reduce_partials(part)
 
 
@@ -156,8 +219,10 @@ def bn_act_bwd_apply(dout, out, y, k1, k2, k3, relu, want_dy=True, want_dz=False
     m = dout.numel() // c
     dy = torch.empty_like(dout) if want_dy else None
     dz = torch.empty_like(dout) if want_dz else None
-    check(lib().maai_bn_act_bwd_apply(_p(dout), _p(out), _p(y), _p(k1), _p(k2), _p(k3), _p(dy), _p(dz), m, c,
-                                      1 if relu else 0, _dt(dout), _stream()), "maai_bn_act_bwd_apply")
+    nt = 1 + (1 if relu else 0) + (1 if k1 is not None else 0) + (1 if want_dy else 0) + (1 if want_dz else 0)
+    with _timed("bn_bwd_apply", 0.0, dout.element_size() * dout.numel() * nt):
+        check(lib().maai_bn_act_bwd_apply(_p(dout), _p(out), _p(y), _p(k1), _p(k2), _p(k3), _p(dy), _p(dz), m, c,
+                                          1 if relu else 0, _dt(dout), _stream()), "maai_bn_act_bwd_apply")
     return dy, dz
 
 
