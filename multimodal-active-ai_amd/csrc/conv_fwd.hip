@@ -8,9 +8,14 @@
 // A/B fragment is one 16-byte run in memory.
 //
 // Tile: BM x BN per 256-thread workgroup (4 waves as 2x2), K-step = 64 bytes per
-// row (32 bf16 / 16 f32).  Global -> registers -> LDS double buffer, one barrier
-// per K-step; LDS rows are 64 B with the st_16x32 XOR swizzle so ds_read_b128
-// fragment reads are bank-conflict free (cdna_hip_programming.md T2).
+// row (32 bf16 / 16 f32).  Staging is LDS-DMA (global_load_lds_dwordx4: no
+// staging VGPRs) into a 4-slot ring with THREE K-steps in flight behind a
+// counted s_waitcnt vmcnt(N) and ONE raw s_barrier per K-step
+// (cdna_hip_programming.md §5 "Pipelining across barriers", T3/T4).  The DMA
+// destination is lane-linear, so the st_16x32 XOR swizzle that makes the
+// ds_read_b128 fragment reads bank-conflict free (T2) is applied to the per-lane
+// SOURCE address and to the read (rule 21).  Padding / out-of-range rows source
+// a 64-byte zero page instead of being predicated.
 // MFMA: v_mfma_f32_16x16x32_bf16 (bf16 storage) or 4x v_mfma_f32_16x16x4_f32
 // (f32 storage, exact fp32 — the parity mode), fp32 accumulation in both.
 // Epilogue: accumulators -> LDS -> 16-byte row-contiguous stores (full 128-B
@@ -39,6 +44,8 @@ template <> struct Mma<float> {
     return c;
   }
 };
+
+__device__ uint4 g_zero64[4];  // zero page for padding / out-of-range lanes of the LDS-DMA loads
 
 struct ConvArgs {
   const void* x;
@@ -75,8 +82,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
   const int K = a.KH * a.KW * a.Cin;
-  const int chunk = tid & 3;
   const int r0 = tid >> 2;
+  // LDS slot (row r, chunk tid&3) holds source chunk (tid&3) ^ swz(r): inverse swizzle on the SOURCE
+  const int chunk = (tid & 3) ^ (((r0 >> 3) & 1) << 1);
 
   // ---- per-thread row decode (fixed for the whole K loop) ----
   long long abase[AR];
@@ -102,37 +110,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < BR; ++i) wp[i] = w + (long long)(nb * BN + r0 + 64 * i) * K + chunk * EPC;
 
-  uint4 ra[AR], rb[BR];
-  int kh = 0, kw = 0, c0 = 0;  // position of the NEXT tile to load
+  int kh = 0, kw = 0, c0 = 0;  // position of the NEXT stage to issue
   const int KT = K / BK;
+  constexpr int NSTAGE = 4;
+  constexpr int NL = AR + BR;  // LDS-DMA instructions per thread per stage
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  const T* zsrc = reinterpret_cast<const T*>(g_zero64);
 
-  auto load_tile = [&](int kt) {
+  auto issue_stage = [&](int kt, int slot) {
     const long long tapoff = ((long long)kh * a.IW + kw) * a.Cin + c0;
+    char* sa = smem + slot * STAGE + widu * 1024;
+    char* sb = sa + BM * 64;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = (unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(x + abase[i] + tapoff) : make_uint4(0, 0, 0, 0);
+      const T* src = ok ? (x + abase[i] + tapoff) : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const uint4*>(wp[i] + (long long)kt * BK);
+    for (int i = 0; i < BR; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + (long long)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
     c0 += BK;
     if (c0 >= a.Cin) {
       c0 = 0;
       if (++kw >= a.KW) { kw = 0; ++kh; }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* sa = smem + buf * STAGE;
-    char* sb = sa + BM * 64;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int r = r0 + 64 * i;
-      *reinterpret_cast<uint4*>(sa + r * 64 + ((chunk ^ (((r >> 3) & 1) << 1)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int r = r0 + 64 * i;
-      *reinterpret_cast<uint4*>(sb + r * 64 + ((chunk ^ (((r >> 3) & 1) << 1)) << 4)) = rb[i];
     }
   };
 
@@ -146,15 +149,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int frow = lane & 15;
   const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) << 1)) << 4);
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  const int pre = KT < NSTAGE - 1 ? KT : NSTAGE - 1;
+  for (int s = 0; s < pre; ++s) issue_stage(s, s);
 
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const char* sa = smem + buf * STAGE + (wm * WM) * 64 + foff;
-    const char* sb = smem + buf * STAGE + BM * 64 + (wn * WN) * 64 + foff;
+    // stages kt+1 .. min(KT-1, kt+2) may stay in flight; stage kt must have landed
+    const int ahead = KT - 1 - kt;
+    if (ahead >= 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+    } else if (ahead == 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // everyone has finished reading slot (kt-1)%4 -> refill it with stage kt+3
+    if (kt + NSTAGE - 1 < KT) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) & (NSTAGE - 1));
+    const int slot = kt & (NSTAGE - 1);
+    const char* sa = smem + slot * STAGE + (wm * WM) * 64 + foff;
+    const char* sb = smem + slot * STAGE + BM * 64 + (wn * WN) * 64 + foff;
     frag_t af[TM], bfr[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * 16 * 64);
@@ -164,9 +177,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
-    if (kt + 1 < KT) store_tile(buf ^ 1);
-    __syncthreads();
   }
+  __syncthreads();  // all DMA retired (vmcnt(0) above); the ring is now reused as the C tile
 
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 template <typename T, int BM, int BN>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int stage = 2 * (BM + BN) * 64;
+  constexpr int stage = 4 * (BM + BN) * 64;
   constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 4 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
