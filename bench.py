@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--temperature", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
     ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
@@ -104,7 +104,11 @@ def make_step(args, model, opt, device, rank, world):
 def cpu_baseline(args):
     """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload."""
     from oracle import simclr_oracle as O
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))  # a one-GPU box's CPU share is 16 cores
     b = args.cpu_batch
     exp = O.expansion(args.arch)
     sd = O.pattern_state_dict(args.arch, 1, 512 * exp * 16)
@@ -112,10 +116,13 @@ def cpu_baseline(args):
     x1 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
     x2 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
     opt = {}
-    O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)  # warm-up
+    sys.stderr.write("[bench] cpu baseline: %d threads, batch %d ...\n" % (torch.get_num_threads(), b))
+    sys.stderr.flush()
     t0 = time.time()
-    for _ in range(args.cpu_steps):
+    for i in range(args.cpu_steps):
         O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)
+        sys.stderr.write("[bench] cpu baseline step %d done at %.1f s\n" % (i, time.time() - t0))
+        sys.stderr.flush()
     dt = (time.time() - t0) / args.cpu_steps
     return dict(value=round(b / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
                 sample="%s 3x%dx%d, batch %d, %d steps (fp32, torch-CPU oracle)" % (args.arch, args.img, args.img, b, args.cpu_steps))

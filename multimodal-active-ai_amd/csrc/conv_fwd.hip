@@ -63,7 +63,7 @@ struct ConvArgs {
   int nMB, nNB;
 };
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   int kh = 0, kw = 0, c0 = 0;  // position of the NEXT stage to issue
   const int KT = K / BK;
-  constexpr int NSTAGE = 4;
   constexpr int NL = AR + BR;  // LDS-DMA instructions per thread per stage
   const int widu = __builtin_amdgcn_readfirstlane(wid);
   const T* zsrc = reinterpret_cast<const T*>(g_zero64);
@@ -155,17 +154,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int kt = 0; kt < KT; ++kt) {
     // stages kt+1 .. min(KT-1, kt+2) may stay in flight; stage kt must have landed
     const int ahead = KT - 1 - kt;
-    if (ahead >= 2) {
+    if (NSTAGE >= 4 && ahead >= 2) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-    } else if (ahead == 1) {
+    } else if (NSTAGE >= 3 && ahead >= 1) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    // everyone has finished reading slot (kt-1)%4 -> refill it with stage kt+3
-    if (kt + NSTAGE - 1 < KT) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) & (NSTAGE - 1));
-    const int slot = kt & (NSTAGE - 1);
+    // everyone has finished reading slot (kt-1)%NSTAGE -> refill it with stage kt+NSTAGE-1
+    if (kt + NSTAGE - 1 < KT) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+    const int slot = kt % NSTAGE;
     const char* sa = smem + slot * STAGE + (wm * WM) * 64 + foff;
     const char* sb = smem + slot * STAGE + BM * 64 + (wn * WN) * 64 + foff;
     frag_t af[TM], bfr[TN];
@@ -252,22 +251,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int BM, int BN>
-static int launch_conv(const ConvArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int NSTAGE>
+static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int stage = 4 * (BM + BN) * 64;
+  constexpr int stage = NSTAGE * (BM + BN) * 64;
   constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 4 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
+}
+
+// ring depth by K extent: short K loops (the HBM-bound 1x1 convolutions) never fill a deep ring and are
+// better served by more resident workgroups per CU (LDS is what limits them)
+template <typename T, int BM, int BN>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  const int kt = a.KH * a.KW * a.Cin * (int)sizeof(T) / 64;
+  if (kt <= 2) return launch_conv_n<T, BM, BN, 2>(a, st);
+  if (kt <= 4) return launch_conv_n<T, BM, BN, 3>(a, st);
+  return launch_conv_n<T, BM, BN, 4>(a, st);
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
