@@ -24,6 +24,7 @@
 // partials for BatchNorm (one deterministic slab row per M-block, no atomics).
 #include "common.h"
 #include "maai_internal.h"
+#include <stdlib.h>
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -274,9 +275,14 @@ static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
 template <typename T, int BM, int BN>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int kt = a.KH * a.KW * a.Cin * (int)sizeof(T) / 64;
+  static const int forced = getenv("MAAI_CONV_NSTAGE") ? atoi(getenv("MAAI_CONV_NSTAGE")) : 0;  // tuning knob
+  if (forced == 2) return launch_conv_n<T, BM, BN, 2>(a, st);
+  if (forced == 3) return launch_conv_n<T, BM, BN, 3>(a, st);
+  if (forced == 4) return launch_conv_n<T, BM, BN, 4>(a, st);
   if (kt <= 2) return launch_conv_n<T, BM, BN, 2>(a, st);
-  if (kt <= 4) return launch_conv_n<T, BM, BN, 3>(a, st);
-  return launch_conv_n<T, BM, BN, 4>(a, st);
+  // measured on MI355X (scripts/conv_micro.py): 3 slots (48 KB -> 3 workgroups per CU) beat 4 on every
+  // ResNet-50 layer shape, including the K = 4608 3x3 convolutions (788 vs 770 TFLOP/s)
+  return launch_conv_n<T, BM, BN, 3>(a, st);
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
