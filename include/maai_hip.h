@@ -69,6 +69,10 @@ long long maai_conv2d_stats_rows(const maai_conv_desc* d);
  * dw is fp32 [Cout][KH][KW][Cin] and must be zeroed by the caller (split-K
  * partial products are added with fp32 atomics). dy is dense [N,OH,OW,Cout]. */
 int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype, void* stream);
+/* Same, with the split-K workgroup budget as a tuning knob (0 = default): more workgroups hide latency,
+ * fewer add less fp32-atomic traffic; the host side measures once per shape and caches the choice. */
+int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype,
+                            int target_blocks, void* stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm (training) — nn.BatchNorm2d / nn.SyncBatchNorm as norm_layer

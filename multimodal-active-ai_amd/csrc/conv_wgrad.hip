@@ -15,6 +15,7 @@
 // ds_read_b32 of the pixel-major tile (pitch BC+16 words, conflict-free).
 #include "common.h"
 #include "maai_internal.h"
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -175,6 +176,222 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
       }
 }
 
+
+// ---------------------------------------------------------------------------
+// bf16 production kernel: LDS-DMA ring (global_load_lds_dwordx4, 3 slots, counted
+// vmcnt, one raw s_barrier per 32-pixel K-step).  Columns are the FLATTENED
+// (tap, ci) index n' in [0, KH*KW*Cin), so narrow layers (Cin = 64, the 7x1 stem)
+// still fill a 128-wide tile; dw[co][n'] is the output address as is.
+// The DMA destination is lane-linear, so tiles are unpadded [32 pixels][BC] with a
+// 16-byte-chunk XOR swizzle applied to the per-lane SOURCE and to the transposed
+// ds_read_b64_tr_b16 reads: chunk' = chunk ^ 2*(row&7) (256-B rows) or
+// chunk ^ 2*((row>>1)&3) (128-B rows) -> the 32 lanes of one read hit 32 distinct
+// 8-byte slots of the 256-B bank row.
+// ---------------------------------------------------------------------------
+__device__ uint4 g_wzero64[4];
+
+template <int BC>
+__device__ __forceinline__ int swz(int row) {
+  return BC == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+}
+
+template <int BCO, int BCN>
+__global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
+  constexpr int PK = 32, NSTAGE = 3;
+  constexpr int RBY = BCO * 2, RBX = BCN * 2;           // row bytes
+  constexpr int TILE_Y = PK * RBY, TILE_X = PK * RBX, STAGE = TILE_Y + TILE_X;
+  constexpr int CPRY = BCO / 8, CPRX = BCN / 8;         // 16-byte chunks per row
+  constexpr int NLY = PK * CPRY / 256, NLX = PK * CPRX / 256;
+  constexpr int NL = NLY + NLX;
+  constexpr int WCO = BCO / 2, WCN = BCN / 2, TM = WCO / 16, TN = WCN / 16;
+  static_assert(NLY >= 1 && NLX >= 1, "tile too small for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int KN = a.KH * a.KW * a.Cin;
+  // XCD-aware decode (speed only): blocks b and b+8 share an XCD, so all tiles of one pixel split get
+  // ids that differ by multiples of 8 -> they run on ONE XCD and share its L2 copy of the dY / x panels.
+  const int ntiles = a.nCoB * a.nCiB;
+  const int bid = blockIdx.x;
+  const int split_id = (bid & 7) + 8 * (bid / (8 * ntiles));
+  const int tile_id = (bid >> 3) % ntiles;
+  const int cnb = tile_id % a.nCiB, cob = tile_id / a.nCiB;
+  const int co0 = cob * BCO, cn0 = cnb * BCN;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_wzero64);
+  const long long ps64 = (long long)split_id * a.pix_per_split;
+  if (ps64 >= a.M) return;  // padding block of the last group of 8 splits
+  const int ps = (int)ps64;
+  int pe = ps + a.pix_per_split;
+  if (pe > a.M) pe = a.M;
+  const int ohw = a.OH * a.OW;
+  const bool dense = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0);
+
+  // ---- per-thread DMA slots (fixed): dY ----
+  int yrow[NLY];
+  long long yoff[NLY];
+#pragma unroll
+  for (int i = 0; i < NLY; ++i) {
+    const int sidx = tid + 256 * i;
+    yrow[i] = sidx / CPRY;
+    const int ch = (sidx % CPRY) ^ swz<BCO>(yrow[i]);
+    yoff[i] = co0 + ch * 8;
+  }
+  // ---- X: column -> (tap, ci) fixed per slot; pixel (n, oh, ow) advances by PK per stage ----
+  int xrow[NLX], xkh[NLX], xkw[NLX], xci[NLX], pn[NLX], poh[NLX], pow_[NLX];
+  bool xcol_ok[NLX];
+#pragma unroll
+  for (int i = 0; i < NLX; ++i) {
+    const int sidx = tid + 256 * i;
+    xrow[i] = sidx / CPRX;
+    const int ch = (sidx % CPRX) ^ swz<BCN>(xrow[i]);
+    const int ncol = cn0 + ch * 8;
+    xcol_ok[i] = ncol < KN;
+    const int tap = ncol / a.Cin;
+    xci[i] = ncol - tap * a.Cin;
+    xkh[i] = tap / a.KW;
+    xkw[i] = tap - xkh[i] * a.KW;
+    const int m = ps + xrow[i];
+    pn[i] = m / ohw;
+    const int rem = m - pn[i] * ohw;
+    poh[i] = rem / a.OW;
+    pow_[i] = rem - poh[i] * a.OW;
+  }
+
+  auto issue_stage = [&](int p0, int slot) {
+    char* sy = smem + slot * STAGE + widu * 1024;
+    char* sx = smem + slot * STAGE + TILE_Y + widu * 1024;
+#pragma unroll
+    for (int i = 0; i < NLY; ++i) {
+      const int m = p0 + yrow[i];
+      const bf16_t* src = (m < pe) ? dy + (long long)m * a.Cout + yoff[i] : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sy + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int m = p0 + xrow[i];
+      const bf16_t* src = zsrc;
+      if (m < pe && xcol_ok[i]) {
+        if (dense) {
+          src = x + (long long)m * a.Cin + xci[i];
+        } else {
+          const int ih = poh[i] * a.stride - a.pad_h + xkh[i], iw = pow_[i] * a.stride - a.pad_w + xkw[i];
+          if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+            src = x + (((long long)pn[i] * a.IH + ih) * a.IW + iw) * a.Cin + xci[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sx + i * 4096), 16, 0, 0);
+      if (!dense) {  // advance this slot's pixel by PK
+        pow_[i] += PK;
+        while (pow_[i] >= a.OW) {
+          pow_[i] -= a.OW;
+          if (++poh[i] == a.OH) { poh[i] = 0; ++pn[i]; }
+        }
+      }
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, g = lane >> 4;
+  const int q = li >> 2, p = li & 3;
+  const int nsteps = (pe - ps + PK - 1) / PK;
+  if (nsteps <= 0) return;
+  const int pre = nsteps < NSTAGE - 1 ? nsteps : NSTAGE - 1;
+  for (int s = 0; s < pre; ++s) issue_stage(ps + s * PK, s);
+
+  // transposed-read byte offsets (row 4g+q and 16+4g+q), independent of the K-step
+  const int r_lo = 4 * g + q, r_hi = 16 + 4 * g + q;
+  for (int s = 0; s < nsteps; ++s) {
+    if (nsteps - 1 - s >= 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (s + NSTAGE - 1 < nsteps) issue_stage(ps + (s + NSTAGE - 1) * PK, (s + NSTAGE - 1) % NSTAGE);
+    const char* sy = smem + (s % NSTAGE) * STAGE;
+    const char* sx = sy + TILE_Y;
+    bf16x8 af[TM], bfr[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int c = (wm * WCO + i * 16) / 8 + (p >> 1);
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sy + r_lo * RBY + ((c ^ swz<BCO>(r_lo)) << 4) + ((p & 1) << 3)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sy + r_hi * RBY + ((c ^ swz<BCO>(r_hi)) << 4) + ((p & 1) << 3)));
+      af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = (wn * WCN + j * 16) / 8 + (p >> 1);
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sx + r_lo * RBX + ((c ^ swz<BCN>(r_lo)) << 4) + ((p & 1) << 3)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(sx + r_hi * RBX + ((c ^ swz<BCN>(r_hi)) << 4) + ((p & 1) << 3)));
+      bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * WCO + i * 16 + 4 * g + r;
+        const int nc = cn0 + wn * WCN + j * 16 + li;
+        if (nc < KN) atomicAdd(a.dw + (long long)co * KN + nc, acc[i][j][r]);
+      }
+}
+
+template <int BCO, int BCN>
+static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
+  constexpr int PK = 32, NSTAGE = 3;
+  constexpr int lds = NSTAGE * PK * (BCO * 2 + BCN * 2);
+  const int KN = a.KH * a.KW * a.Cin;
+  a.nCoB = a.Cout / BCO;
+  a.nCiB = (KN + BCN - 1) / BCN;
+  a.nTap = 1;
+  const long long tiles = (long long)a.nCoB * a.nCiB;
+  const int ksteps = (a.M + PK - 1) / PK;
+  // split-K count: every split adds Cout*KN*4 bytes of fp32 atomics, which run at ~1.3 TB/s chip-wide
+  // (MI355X_MICROARCH.md "Global float atomics"), so keep just enough workgroups to fill the chip once
+  // (3 resident per CU x 256 CUs) instead of many short ones.
+  if (target <= 0) target = 1536;
+  long long split = (target + tiles - 1) / tiles;
+  if (split > ksteps / 8) split = ksteps / 8;
+  if (split < 1) split = 1;
+  if (split > 65535) split = 65535;
+  const int steps_per = (int)((ksteps + split - 1) / split);
+  a.pix_per_split = steps_per * PK;
+  const int ny = (a.M + a.pix_per_split - 1) / a.pix_per_split;
+  const int ny8 = (ny + 7) / 8 * 8;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN>), dim3((unsigned)(tiles * ny8)), dim3(256), lds, st, a);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+static int dispatch_wgrad_bf16(const WgradArgs& a, hipStream_t st, int target) {
+  const int KN = a.KH * a.KW * a.Cin;
+  const bool co128 = a.Cout % 128 == 0;
+  if (KN >= 128) return co128 ? launch_wgrad_ring<128, 128>(a, st, target) : launch_wgrad_ring<64, 128>(a, st, target);
+  return co128 ? launch_wgrad_ring<128, 64>(a, st, target) : launch_wgrad_ring<64, 64>(a, st, target);
+}
+
 template <typename T, int BCO, int BCI>
 static int launch_wgrad(WgradArgs a, hipStream_t st) {
   constexpr bool BF = sizeof(T) == 2;
@@ -213,6 +430,11 @@ static int dispatch_wgrad(const WgradArgs& a, hipStream_t st) {
 }
 
 extern "C" int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype, void* stream) {
+  return maai_conv2d_wgrad_tuned(d, x, dy, dw, dtype, 0, stream);
+}
+
+extern "C" int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype,
+                                       int target_blocks, void* stream) {
   MAAI_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: null pointer");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_wgrad: dtype must be MAAI_BF16 or MAAI_F32");
   MAAI_CHECK_ARG(d->Cin % 32 == 0, "conv2d_wgrad: Cin must be a multiple of 32");
@@ -227,5 +449,6 @@ extern "C" int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const v
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OH = d->OH; a.OW = d->OW;
   a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY")) return dispatch_wgrad_bf16(a, st, target_blocks);
   return dtype == MAAI_BF16 ? dispatch_wgrad<bf16_t>(a, st) : dispatch_wgrad<float>(a, st);
 }

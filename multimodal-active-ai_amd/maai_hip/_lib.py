@@ -34,6 +34,7 @@ SIGNATURES = {
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
+    "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),
     "maai_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),

@@ -6,6 +6,7 @@ torch.bfloat16 (production) or torch.float32 (exact-fp32 parity mode).
 No fallback: every wrapper raises ``MaaiError`` for non-HIP tensors.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -130,16 +131,48 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     return (out, part) if stats else out
 
 
+_WGRAD_TUNE = {}
+WGRAD_CANDIDATES = (768, 1536, 3072)
+AUTOTUNE = [os.environ.get("MAAI_AUTOTUNE", "1") != "0"]
+
+
+def _wgrad_target(d, x, dy, dtype_code):
+    """Split-K workgroup budget for this shape: measured once (HIP events), then cached."""
+    if dtype_code != BF16 or not AUTOTUNE[0] or torch.cuda.is_current_stream_capturing():
+        return 0
+    key = (d.N, d.IH, d.IW, d.Cin, d.Cout, d.KH, d.KW, d.stride)
+    hit = _WGRAD_TUNE.get(key)
+    if hit is not None:
+        return hit
+    tmp = torch.zeros((d.Cout, d.KH, d.KW, d.Cin), dtype=torch.float32, device=x.device)
+    best, best_ms = 0, None
+    for cand in WGRAD_CANDIDATES:
+        ms = []
+        for rep in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().maai_conv2d_wgrad_tuned(C.byref(d), _p(x), _p(dy), _p(tmp), dtype_code, cand, _stream()), "maai_conv2d_wgrad_tuned")
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        m = min(ms[1:])
+        if best_ms is None or m < best_ms:
+            best, best_ms = cand, m
+    _WGRAD_TUNE[key] = best
+    return best
+
+
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
     """dw[Cout,KH,KW,Cin] fp32 for y = conv(x, w); dy dense [N,OH,OW,Cout]."""
     _gpu(x, dy)
     n, ih, iw, cin = x.shape
     _, oh, ow, cout = dy.shape
     d = ConvDesc(n, ih, iw, cin, cout, kh, kw, stride, pad_h, pad_w, oh, ow, oh, ow, 1, 0, 0, 0)
+    target = _wgrad_target(d, x, dy, _dt(x))
     dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     nm = "conv_wgrad" if not DETAIL[0] else "conv_wgrad M%d Cin%d Cout%d k%dx%d s%d" % (dy.numel() // cout, cin, cout, kh, kw, stride)
     with _timed(nm, 2.0 * dy.numel() * kh * kw * cin * FLOPS_SCALE[0], x.element_size() * (x.numel() + dy.numel()) + 4 * dw.numel()):
-        check(lib().maai_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), _stream()), "maai_conv2d_wgrad")
+        check(lib().maai_conv2d_wgrad_tuned(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), target, _stream()), "maai_conv2d_wgrad_tuned")
     return dw
 
 
