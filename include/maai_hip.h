@@ -46,7 +46,7 @@ int maai_device_count(void);
  *   y : [N, OH, OW, Cout]           written at (oh*out_stride+out_off_h, ow*out_stride+out_off_w)
  *                                   for oh < OHg, ow < OWg; y += result when accumulate != 0
  *   stats_partial (nullable): [maai_conv2d_stats_rows()][2][Cout] fp32 —
- *       per 128-pixel block: sum and sum of squares of the fp32 results per
+ *       per M-tile (64 or 128 pixels, chosen by the library): sum and sum of squares of the fp32 results per
  *       output channel (BatchNorm batch statistics, resnet.py:54,106-110,171).
  * Cin % 32 == 0 (bf16) / % 16 (f32); Cout % 64 == 0.
  * ------------------------------------------------------------------------ */
@@ -62,7 +62,7 @@ typedef struct {
 
 int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                       int dtype, void* stream);
-long long maai_conv2d_stats_rows(const maai_conv_desc* d);
+long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):
  *   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]
@@ -161,8 +161,8 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
 /* ------------------------------------------------------------------------
  * Optimiser (Model_Util.py:68-88: torch.optim.Adam / SGD)
  * ------------------------------------------------------------------------ */
-int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                   float eps, int step, float grad_scale, void* stream);
+int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                   double eps, int step, float grad_scale, void* stream);
 int maai_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float weight_decay,
                   int first_step, void* stream);
 

@@ -37,16 +37,21 @@ extern "C" void maai_set_error(const char* msg);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN-preserving (plain cast semantics)
+// round-to-nearest-even, NaN-preserving: a plain __bf16 cast, which hipcc lowers to v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  const __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, h);
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const bf16x2_hw v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// value of the lane with index lane^1 (DPP quad_perm [1,0,3,2]; no LDS, no wait)
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
 // storage-type traits: T = bf16_t or float

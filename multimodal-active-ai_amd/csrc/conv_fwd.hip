@@ -87,20 +87,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // LDS slot (row r, chunk tid&3) holds source chunk (tid&3) ^ swz(r): inverse swizzle on the SOURCE
   const int chunk = (tid & 3) ^ (((r0 >> 3) & 1) << 1);
 
-  // ---- per-thread row decode (fixed for the whole K loop) ----
+  // ---- per-thread row decode (fixed for the whole K loop); 32-bit arithmetic (M < 2^31 is checked on the host),
+  //      and no decode at all for pointwise stride-1 layers where the input pixel IS the output pixel ----
   long long abase[AR];
   int ihb[AR], iwb[AR];
-  const int ohw = a.OHg * a.OWg;
+  const unsigned ohw = (unsigned)(a.OHg * a.OWg);
+  const bool pointwise = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.OHg == a.IH && a.OWg == a.IW);
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const long long m = (long long)mb * BM + r0 + 64 * i;
     if (m < a.M) {
-      const int n = (int)(m / ohw);
-      const int rem = (int)(m - (long long)n * ohw);
-      const int oh = rem / a.OWg, ow = rem - oh * a.OWg;
-      ihb[i] = oh * a.stride - a.pad_h;
-      iwb[i] = ow * a.stride - a.pad_w;
-      abase[i] = (((long long)n * a.IH + ihb[i]) * a.IW + iwb[i]) * a.Cin + chunk * EPC;
+      if (pointwise) {
+        ihb[i] = 0;
+        iwb[i] = 0;
+        abase[i] = m * a.Cin + chunk * EPC;
+      } else {
+        const unsigned mu = (unsigned)m;
+        const unsigned n = mu / ohw;
+        const unsigned rem = mu - n * ohw;
+        const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
+        ihb[i] = (int)oh * a.stride - a.pad_h;
+        iwb[i] = (int)ow * a.stride - a.pad_w;
+        abase[i] = (((long long)n * a.IH + ihb[i]) * a.IW + iwb[i]) * a.Cin + chunk * EPC;
+      }
     } else {
       ihb[i] = -(1 << 28);
       iwb[i] = -(1 << 28);
@@ -183,16 +192,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
   float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm][2][BN]
+  if constexpr (sizeof(T) == 2) {
+    // Each lane holds 4 rows x 1 column per 16x16 tile.  Lane pairs (l, l^1) swap halves through DPP so that
+    // the even lane owns rows 0,1 and the odd lane rows 2,3 of a 2-column strip: two packed ds_write_b32 per
+    // tile instead of four ds_write_b16, conflict-free within each 32-lane half (row pitch 272 B).
+    uint32_t* ct32 = reinterpret_cast<uint32_t*>(smem);
+    const bool odd = lane & 1;
+    const int colp = ((lane & 15) & ~1) >> 1;  // dword column inside the 16-wide tile
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + r;
-        const int nl = wn * WN + j * 16 + (lane & 15);
-        Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 v = acc[i][j];
+        const float t0 = lane_xor1(odd ? v[0] : v[2]);
+        const float t1 = lane_xor1(odd ? v[1] : v[3]);
+        const uint32_t p0 = odd ? pack_bf16x2(t0, v[2]) : pack_bf16x2(v[0], t0);
+        const uint32_t p1 = odd ? pack_bf16x2(t1, v[3]) : pack_bf16x2(v[1], t1);
+        const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + (odd ? 2 : 0);
+        const int nd = (wn * WN + j * 16) / 2 + colp;
+        ct32[ml * (LDC / 2) + nd] = p0;
+        ct32[(ml + 1) * (LDC / 2) + nd] = p1;
       }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+          const int nl = wn * WN + j * 16 + (lane & 15);
+          Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
+        }
+  }
   if (a.stats) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -230,9 +262,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     if (m >= a.M) continue;
     long long opix = m;
     if (!dense) {
-      const int n = (int)(m / ohw);
-      const int rem = (int)(m - (long long)n * ohw);
-      const int oh = rem / a.OWg, ow = rem - oh * a.OWg;
+      const unsigned mu = (unsigned)m;
+      const unsigned n = mu / ohw;
+      const unsigned rem = mu - n * ohw;
+      const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
       opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
     }
     T* dst = y + opix * a.Cout + nb * BN + ch * EPC;
@@ -285,6 +318,16 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_n<T, BM, BN, 3>(a, st);
 }
 
+// M-tile by K extent: layers with a short K loop are HBM-bound and latency-exposed (load wait, MFMA, LDS
+// epilogue and store drain are serial inside a workgroup), so they get 64-row tiles: half the LDS and
+// accumulator footprint -> twice the resident workgroups per CU to overlap those phases.
+static int choose_bm(const maai_conv_desc* d, int dtype) {
+  static const int forced = getenv("MAAI_CONV_BM") ? atoi(getenv("MAAI_CONV_BM")) : 0;
+  if (forced == 64 || forced == 128) return forced;
+  const int kbytes = d->KH * d->KW * d->Cin * (dtype == MAAI_BF16 ? 2 : 4);
+  return kbytes <= 1024 ? 64 : 128;
+}
+
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                  int dtype, void* stream) {
   MAAI_CHECK_ARG(d && x && w && y, "conv2d_igemm: null pointer");
@@ -303,18 +346,24 @@ extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const v
   a.OH = d->OH; a.OW = d->OW; a.ostr = d->out_stride; a.ooh = d->out_off_h; a.oow = d->out_off_w;
   a.accumulate = d->accumulate;
   a.M = (long long)d->N * d->OHg * d->OWg;
-  a.nMB = (int)((a.M + 127) / 128);
+  MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
+  const int bm = choose_bm(d, dtype);
+  a.nMB = (int)((a.M + bm - 1) / bm);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (d->Cout % 128 == 0) {
-    a.nNB = d->Cout / 128;
-    return dtype == MAAI_BF16 ? launch_conv<bf16_t, 128, 128>(a, st) : launch_conv<float, 128, 128>(a, st);
+  const bool n128 = d->Cout % 128 == 0;
+  a.nNB = d->Cout / (n128 ? 128 : 64);
+  if (dtype == MAAI_BF16) {
+    if (bm == 64) return n128 ? launch_conv<bf16_t, 64, 128>(a, st) : launch_conv<bf16_t, 64, 64>(a, st);
+    return n128 ? launch_conv<bf16_t, 128, 128>(a, st) : launch_conv<bf16_t, 128, 64>(a, st);
   }
-  a.nNB = d->Cout / 64;
-  return dtype == MAAI_BF16 ? launch_conv<bf16_t, 128, 64>(a, st) : launch_conv<float, 128, 64>(a, st);
+  if (bm == 64) return n128 ? launch_conv<float, 64, 128>(a, st) : launch_conv<float, 64, 64>(a, st);
+  return n128 ? launch_conv<float, 128, 128>(a, st) : launch_conv<float, 128, 64>(a, st);
 }
 
-extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d) {
+/* rows of the statistics slab: one per M-tile of the kernel maai_conv2d_igemm picks for (d, dtype) */
+extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {
   if (!d) return 0;
   const long long M = (long long)d->N * d->OHg * d->OWg;
-  return (M + 127) / 128;
+  const int bm = choose_bm(d, dtype);
+  return (M + bm - 1) / bm;
 }

@@ -342,12 +342,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-extern "C" int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                              float eps, int step, float grad_scale, void* stream) {
+extern "C" int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                              double eps, int step, float grad_scale, void* stream) {
   MAAI_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, ST(stream), p, g, m, v, n, (float)(lr / bc1), beta1, beta2,
-                     (float)(1.0 - (double)beta1), (float)(1.0 - (double)beta2), eps, (float)(1.0 / sqrt(bc2)), grad_scale);
+  // hyper-parameters arrive as doubles and are rounded to fp32 once, exactly where torch.optim.Adam rounds them
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(cap_grid(n)), dim3(256), 0, ST(stream), p, g, m, v, n, (float)(lr / bc1), (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

@@ -32,7 +32,7 @@ SIGNATURES = {
     "maai_last_error": (C.c_char_p, []),
     "maai_device_count": (c_i, []),
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_i, c_p]),
-    "maai_conv2d_stats_rows": (c_ll, [_P_DESC]),
+    "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),
@@ -57,7 +57,7 @@ SIGNATURES = {
     "maai_ntxent_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p]),
     "maai_ntxent_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     "maai_ntxent_normalize_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_d, c_d, c_d, c_d, c_i, c_f, c_p]),
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
     "maai_augment_view_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maai_augment_params": (c_i, [c_p, c_i, c_i, c_i, c_ull, c_i, c_f, c_f, c_f, c_f, c_p]),

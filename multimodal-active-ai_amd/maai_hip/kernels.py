@@ -120,7 +120,7 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
         out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
     part = None
     if stats:
-        rows = lib().maai_conv2d_stats_rows(C.byref(d))
+        rows = lib().maai_conv2d_stats_rows(C.byref(d), _dt(x))
         part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
     m = d.N * d.OHg * d.OWg
     es = x.element_size()

@@ -15,7 +15,7 @@ for (cin, cout, hw, k, s) in shapes:
     w = (torch.randn(cout, k, k, cin, device="cuda") / (cin * k * k) ** 0.5).to(torch.bfloat16)
     p = k // 2
     if which == "fwd":
-        fn = lambda: K.conv2d(x, w, s, p, p, stats=True)
+        fn = lambda: K.conv2d(x, w, s, p, p, stats=os.environ.get("STATS", "1") == "1")
     else:
         dy = torch.randn(B, hw, hw, cout, device="cuda").to(torch.bfloat16)
         fn = lambda: K.conv2d_wgrad(x, dy, k, k, s, p, p)
