@@ -318,14 +318,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_n<T, BM, BN, 3>(a, st);
 }
 
-// M-tile by K extent: layers with a short K loop are HBM-bound and latency-exposed (load wait, MFMA, LDS
-// epilogue and store drain are serial inside a workgroup), so they get 64-row tiles: half the LDS and
-// accumulator footprint -> twice the resident workgroups per CU to overlap those phases.
+// M-tile: 128 rows; a 64-row variant (half the LDS / accumulator footprint, twice the resident workgroups)
+// is compiled in and selectable with MAAI_CONV_BM=64 for experiments.
 static int choose_bm(const maai_conv_desc* d, int dtype) {
   static const int forced = getenv("MAAI_CONV_BM") ? atoi(getenv("MAAI_CONV_BM")) : 0;
   if (forced == 64 || forced == 128) return forced;
-  const int kbytes = d->KH * d->KW * d->Cin * (dtype == MAAI_BF16 ? 2 : 4);
-  return kbytes <= 1024 ? 64 : 128;
+  (void)dtype;
+  return 128;  // measured (scripts/conv_micro.py, MAAI_CONV_BM=64): 64-row tiles lose on every ResNet-50 shape
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
