@@ -192,24 +192,24 @@ __device__ uint4 g_wzero64[4];
 
 template <int BC>
 __device__ __forceinline__ int swz(int row) {
-  return BC == 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+  return BC >= 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
 }
 
-template <int BCO, int BCN>
-__global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
-  constexpr int PK = 32, NSTAGE = 3;
+template <int BCO, int BCN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a) {
+  constexpr int PK = 32, NSTAGE = 3, NT = 64 * NWM * NWN;
   constexpr int RBY = BCO * 2, RBX = BCN * 2;           // row bytes
   constexpr int TILE_Y = PK * RBY, TILE_X = PK * RBX, STAGE = TILE_Y + TILE_X;
   constexpr int CPRY = BCO / 8, CPRX = BCN / 8;         // 16-byte chunks per row
-  constexpr int NLY = PK * CPRY / 256, NLX = PK * CPRX / 256;
+  constexpr int NLY = PK * CPRY / NT, NLX = PK * CPRX / NT;
   constexpr int NL = NLY + NLX;
-  constexpr int WCO = BCO / 2, WCN = BCN / 2, TM = WCO / 16, TN = WCN / 16;
-  static_assert(NLY >= 1 && NLX >= 1, "tile too small for 256 threads");
+  constexpr int WCO = BCO / NWM, WCN = BCN / NWN, TM = WCO / 16, TN = WCN / 16;
+  static_assert(NLY >= 1 && NLX >= 1, "tile too small for the thread count");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int widu = __builtin_amdgcn_readfirstlane(wid);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / NWN, wn = wid % NWN;
   const int KN = a.KH * a.KW * a.Cin;
   // XCD-aware decode (speed only): blocks b and b+8 share an XCD, so all tiles of one pixel split get
   // ids that differ by multiples of 8 -> they run on ONE XCD and share its L2 copy of the dY / x panels.
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
   long long yoff[NLY];
 #pragma unroll
   for (int i = 0; i < NLY; ++i) {
-    const int sidx = tid + 256 * i;
+    const int sidx = tid + NT * i;
     yrow[i] = sidx / CPRY;
     const int ch = (sidx % CPRY) ^ swz<BCO>(yrow[i]);
     yoff[i] = co0 + ch * 8;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
   bool xcol_ok[NLX];
 #pragma unroll
   for (int i = 0; i < NLX; ++i) {
-    const int sidx = tid + 256 * i;
+    const int sidx = tid + NT * i;
     xrow[i] = sidx / CPRX;
     const int ch = (sidx % CPRX) ^ swz<BCN>(xrow[i]);
     const int ncol = cn0 + ch * 8;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
       const int m = p0 + yrow[i];
       const bf16_t* src = (m < pe) ? dy + (long long)m * a.Cout + yoff[i] : zsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sy + i * 4096), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sy + i * (NT * 16)), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
         }
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sx + i * 4096), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sx + i * (NT * 16)), 16, 0, 0);
       if (!dense) {  // advance this slot's pixel by PK
         pow_[i] += PK;
         while (pow_[i] >= a.OW) {
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(256) void wgrad_ring_kernel(WgradArgs a) {
       }
 }
 
-template <int BCO, int BCN>
+template <int BCO, int BCN, int NWM, int NWN>
 static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
-  constexpr int PK = 32, NSTAGE = 3;
+  constexpr int PK = 32, NSTAGE = 3, NT = 64 * NWM * NWN;
   constexpr int lds = NSTAGE * PK * (BCO * 2 + BCN * 2);
   const int KN = a.KH * a.KW * a.Cin;
   a.nCoB = a.Cout / BCO;
@@ -364,9 +364,10 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   const long long tiles = (long long)a.nCoB * a.nCiB;
   const int ksteps = (a.M + PK - 1) / PK;
   // split-K count: every split adds Cout*KN*4 bytes of fp32 atomics, which run at ~1.3 TB/s chip-wide
-  // (MI355X_MICROARCH.md "Global float atomics"), so keep just enough workgroups to fill the chip once
-  // (3 resident per CU x 256 CUs) instead of many short ones.
+  // (MI355X_MICROARCH.md "Global float atomics"); more workgroups hide latency better.  The host side
+  // measures a few budgets per shape and caches the best (kernels.py).
   if (target <= 0) target = 1536;
+  if (NT == 512) target = (target + 1) / 2;  // one 8-wave workgroup per CU
   long long split = (target + tiles - 1) / tiles;
   if (split > ksteps / 8) split = ksteps / 8;
   if (split < 1) split = 1;
@@ -377,19 +378,26 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   const int ny8 = (ny + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN>), dim3((unsigned)(tiles * ny8)), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
 
+// Tile choice: every (co-tile, column-tile) pair streams all pixels, so operand traffic is
+// M * (BCO + BCN) * 2 B * (Cout/BCO) * (KN/BCN).  Measured with FETCH_SIZE, the 128x128 tile moved 2.6x the
+// algorithmic bytes (profiles/r01_pmc_traffic_b256.json) and ran at the fabric rate, not the MFMA rate;
+// an 8-wave 256x256 tile halves that but, at one workgroup per CU, measured slower (scripts/conv_micro.py);
+// it stays selectable with MAAI_WGRAD_TILE=256.
 static int dispatch_wgrad_bf16(const WgradArgs& a, hipStream_t st, int target) {
   const int KN = a.KH * a.KW * a.Cin;
+  static const int big = getenv("MAAI_WGRAD_TILE") ? atoi(getenv("MAAI_WGRAD_TILE")) : 128;  // measured: the 8-wave 256x256 tile is slower (1 workgroup per CU)
+  if (big == 256 && a.Cout % 256 == 0 && KN >= 256 && a.M >= 16384) return launch_wgrad_ring<256, 256, 2, 4>(a, st, target);
   const bool co128 = a.Cout % 128 == 0;
-  if (KN >= 128) return co128 ? launch_wgrad_ring<128, 128>(a, st, target) : launch_wgrad_ring<64, 128>(a, st, target);
-  return co128 ? launch_wgrad_ring<128, 64>(a, st, target) : launch_wgrad_ring<64, 64>(a, st, target);
+  if (KN >= 128) return co128 ? launch_wgrad_ring<128, 128, 2, 2>(a, st, target) : launch_wgrad_ring<64, 128, 2, 2>(a, st, target);
+  return co128 ? launch_wgrad_ring<128, 64, 2, 2>(a, st, target) : launch_wgrad_ring<64, 64, 2, 2>(a, st, target);
 }
 
 template <typename T, int BCO, int BCI>
