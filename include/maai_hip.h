@@ -48,6 +48,9 @@ int maai_device_count(void);
  *   stats_partial (nullable): [maai_conv2d_stats_rows()][2][Cout] fp32 —
  *       per M-tile (64 or 128 pixels, chosen by the library): sum and sum of squares of the fp32 results per
  *       output channel (BatchNorm batch statistics, resnet.py:54,106-110,171).
+ *   relu_mask (nullable): tensor laid out like y; the stored result is zeroed where relu_mask <= 0.
+ *       Used by the data gradients: y is then d(loss)/d(t) for a post-ReLU tensor t = relu_mask, and the
+ *       ReLU backward (resnet.py:55,111,133 under autograd) is folded into this epilogue.
  * Cin % 32 == 0 (bf16) / % 16 (f32); Cout % 64 == 0.
  * ------------------------------------------------------------------------ */
 typedef struct {
@@ -61,7 +64,7 @@ typedef struct {
 } maai_conv_desc;
 
 int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
-                      int dtype, void* stream);
+                      const void* relu_mask, int dtype, void* stream);
 long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):

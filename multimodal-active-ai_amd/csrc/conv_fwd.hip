@@ -53,6 +53,7 @@ struct ConvArgs {
   const void* w;
   void* y;
   float* stats;
+  const void* mask;  // optional: output *= (mask > 0), same layout as y (ReLU gradient of the tensor y is the gradient of)
   long long M;
   int N, IH, IW, Cin;
   int Cout, KH, KW;
@@ -268,17 +269,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
       opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
     }
-    T* dst = y + opix * a.Cout + nb * BN + ch * EPC;
+    const long long ooff = opix * a.Cout + nb * BN + ch * EPC;
+    T* dst = y + ooff;
     Vec16<T> v;
     v.load(ct + row * LDC + ch * EPC);
-    if (a.accumulate) {
-      Vec16<T> o;
-      o.load(dst);
-      float fv[Vec16<T>::N], fo[Vec16<T>::N];
+    if (a.accumulate || a.mask) {
+      float fv[Vec16<T>::N];
       v.get(fv);
-      o.get(fo);
+      if (a.accumulate) {
+        Vec16<T> o;
+        o.load(dst);
+        float fo[Vec16<T>::N];
+        o.get(fo);
 #pragma unroll
-      for (int e = 0; e < Vec16<T>::N; ++e) fv[e] += fo[e];
+        for (int e = 0; e < Vec16<T>::N; ++e) fv[e] += fo[e];
+      }
+      if (a.mask) {
+        Vec16<T> mk;
+        mk.load(reinterpret_cast<const T*>(a.mask) + ooff);
+        float fm[Vec16<T>::N];
+        mk.get(fm);
+#pragma unroll
+        for (int e = 0; e < Vec16<T>::N; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
+      }
       v.set(fv);
     }
     v.store(dst);
@@ -328,7 +341,7 @@ static int choose_bm(const maai_conv_desc* d, int dtype) {
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
-                                 int dtype, void* stream) {
+                                 const void* relu_mask, int dtype, void* stream) {
   MAAI_CHECK_ARG(d && x && w && y, "conv2d_igemm: null pointer");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_igemm: dtype must be MAAI_BF16 or MAAI_F32");
   const int bk = dtype == MAAI_BF16 ? 32 : 16;
@@ -339,7 +352,7 @@ extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const v
   MAAI_CHECK_ARG((d->OHg - 1) * d->out_stride + d->out_off_h < d->OH && (d->OWg - 1) * d->out_stride + d->out_off_w < d->OW,
                  "conv2d_igemm: output scatter exceeds the output tensor");
   ConvArgs a;
-  a.x = x; a.w = w; a.y = y; a.stats = stats_partial;
+  a.x = x; a.w = w; a.y = y; a.stats = stats_partial; a.mask = relu_mask;
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OHg = d->OHg; a.OWg = d->OWg;
   a.OH = d->OH; a.OW = d->OW; a.ostr = d->out_stride; a.ooh = d->out_off_h; a.oow = d->out_off_w;

@@ -31,7 +31,7 @@ SIGNATURES = {
     "maai_abi_version": (c_i, []),
     "maai_last_error": (C.c_char_p, []),
     "maai_device_count": (c_i, []),
-    "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -108,9 +108,9 @@ def make_desc(x, w, stride, pad_h, pad_w, grid_hw=None, out_hw=None, out_stride=
 
 
 def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None, out_hw=None, out_stride=1,
-           out_off=(0, 0), accumulate=False):
-    """y = conv(x, w) (NHWC / KHWC).  Returns y or (y, stats_partial[rows,2,Cout])."""
-    _gpu(x, w, out)
+           out_off=(0, 0), accumulate=False, relu_mask=None):
+    """y = conv(x, w) (NHWC / KHWC), optionally y *= (relu_mask > 0).  Returns y or (y, stats_partial[rows,2,Cout])."""
+    _gpu(x, w, out, relu_mask)
     if x.dtype != w.dtype:
         raise MaaiError("conv2d: x and w must share the storage dtype")
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
@@ -125,9 +125,12 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     m = d.N * d.OHg * d.OWg
     es = x.element_size()
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
+    if relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
+        raise MaaiError("conv2d: relu_mask must have the output's shape and dtype")
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
-                es * (x.numel() + w.numel() + m * d.Cout * (2 if accumulate else 1))):
-        check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _dt(x), _stream()), "maai_conv2d_igemm")
+                es * (x.numel() + w.numel() + m * d.Cout * (1 + (1 if accumulate else 0) + (1 if relu_mask is not None else 0)))):
+        check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), _dt(x), _stream()),
+              "maai_conv2d_igemm")
     return (out, part) if stats else out
 
 

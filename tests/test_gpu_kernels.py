@@ -384,3 +384,27 @@ def test_augment_bit_exact(K):
     p2 = K.augment_params(6, 64, 48, seed=77, view=2, device="cuda").cpu()
     p1 = K.augment_params(6, 64, 48, seed=77, view=1, device="cuda").cpu()
     assert torch.equal(p1, pc) and not torch.equal(p2, pc)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_conv_relu_mask_epilogue(K, dtype):
+    """y = conv(x, w) * (mask > 0), alone and combined with accumulate + strided scatter."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 64, 9, 9, generator=g)
+    wt = torch.randn(128, 64, 3, 3, generator=g) / 24
+    mask = torch.randn(2, 128, 9, 9, generator=g)
+    if dtype == torch.bfloat16:
+        x, wt, mask = rb(x), rb(wt), rb(mask)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1) * (mask > 0)
+    y = K.conv2d(nhwc(x, dtype), khwc(wt, dtype), 1, 1, 1, relu_mask=nhwc(mask, dtype))
+    np.testing.assert_allclose(from_nhwc(y).numpy(), ref.float().numpy(), **tol(dtype))
+    base = torch.randn(2, 128, 17, 17, generator=g)
+    mask2 = torch.randn(2, 128, 17, 17, generator=g)
+    if dtype == torch.bfloat16:
+        base, mask2 = rb(base), rb(mask2)
+    out = nhwc(base, dtype)
+    K.conv2d(nhwc(x, dtype), khwc(wt, dtype), 1, 1, 1, out=out, grid_hw=(9, 9), out_hw=(17, 17), out_stride=2, accumulate=True,
+             relu_mask=nhwc(mask2, dtype))
+    ref2 = base.clone().double()
+    ref2[:, :, 0::2, 0::2] = (ref2[:, :, 0::2, 0::2] + F.conv2d(x.double(), wt.double(), None, 1, 1)) * (mask2[:, :, 0::2, 0::2] > 0)
+    np.testing.assert_allclose(from_nhwc(out).numpy(), ref2.float().numpy(), **tol(dtype))

@@ -230,7 +230,10 @@ def test_every_block_teacher_forced(mods, arch, cm, shape, prec):
             dout = dout.to(torch.bfloat16).float()
         ref.backward(dout)
         grads = {}
-        dx = engine.block_bwd(entry, dout.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), grads, dtype)
+        # engine convention: the incoming gradient already carries the block output's ReLU mask and the
+        # returned one carries the block input's (both folded into conv epilogues on the real path)
+        dmask = engine.relu_mask_grad(dout.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), r3.out)
+        dx = engine.block_bwd(entry, dmask, grads, dtype)
         torch.cuda.synchronize()
 
         def direction(got_t, ref_t, name):
@@ -238,7 +241,7 @@ def test_every_block_teacher_forced(mods, arch, cm, shape, prec):
             c = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
             assert c > gcos, (blk["prefix"], name, c)
             assert abs((a.norm() / b.norm()).item() - 1) < (3e-2 if prec == "bf16" else 1e-2), (blk["prefix"], name)
-        direction(_nchw(dx), xr.grad, "dx")
+        direction(_nchw(dx), xr.grad * (x_in > 0), "dx")
         named = dict(m.f.named_parameters())
         for k in keys:
             p = named[k[2:]]
