@@ -200,6 +200,18 @@ def main():
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, launches=t["launches"],
                         avg_launch_ms=round(t["ms"] / t["launches"], 4), share_of_step=round(t["ms"] / ms, 3))
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+    # figure measured for THIS command by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
+    # correction applied) is read from the committed summary when the workload matches; otherwise null.
+    if roof is not None and args.arch == "resnet50" and args.img == 224 and args.batch == 256:
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b256.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                k = json.load(fh)["kernels"].get(roof["kernel"])
+            if k:
+                roof["traffic"] = round(k["hbm_bytes_per_launch"] / 1e9, 3)
+                roof["traffic_unit"] = "GB/launch (PMC, profiles/r01_pmc_traffic_b256.json)"
+                roof["algorithmic_GB_per_launch"] = round(table[roof["kernel"]]["bytes"] / table[roof["kernel"]]["launches"] / 1e9, 3)
     if rank == 0 and args.profile_table:
         with open(args.profile_table, "w") as fh:
             json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in table.items()}, fh, indent=1)

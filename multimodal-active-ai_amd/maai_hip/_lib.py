@@ -74,6 +74,17 @@ def lib():
     """Load (once) and return the shared library; raise loudly if it is absent."""
     global _LIB
     if _LIB is None:
+        if not os.path.exists(LIB_PATH) and os.environ.get("MAAI_NO_AUTOBUILD", "0") != "1":
+            # the library is an in-tree build product: compile it (hipcc, ~10 s) rather than fail when only
+            # the sources travelled; there is still no non-HIP fallback.
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("maai_build", os.path.join(PKG_ROOT, "build.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise MaaiError("libmaai_hip.so is missing and could not be built: %s" % e)
         if not os.path.exists(LIB_PATH):
             raise MaaiError(
                 "libmaai_hip.so is missing (%s). Build it with `python multimodal-active-ai_amd/build.py` "
