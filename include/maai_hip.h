@@ -67,6 +67,28 @@ int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, voi
                       const void* relu_mask, int dtype, void* stream);
 long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
 
+/* Fused epilogues for the HBM-bound pointwise layers: the GEMM is cheap next to its output traffic, so it is
+ * run twice instead of materialising the raw conv output (resnet.py:109-110,130-133: conv3 -> bn3 -> += identity
+ * -> relu):  forward = STATS_ONLY pass (no store) + BN_ACT pass (out = act(y*scale + shift (+ residual)));
+ * backward = BWD_REDUCE pass (partial sums of dz and dz*(y-mean), same slab format as stats_partial) +
+ * BWD_APPLY pass (dy = k1*dz - k2 - k3*y).  y is the bf16/f32-rounded accumulator, exactly the value the
+ * unfused path would have stored. */
+#define MAAI_EPI_STORE 0
+#define MAAI_EPI_STATS_ONLY 1
+#define MAAI_EPI_BN_ACT 2
+#define MAAI_EPI_BWD_REDUCE 3
+#define MAAI_EPI_BWD_APPLY 4
+typedef struct {
+  int mode;
+  int relu;          /* BN_ACT: apply max(.,0) */
+  const float* p0;   /* BN_ACT: scale (NULL = 1); BWD_REDUCE: mean (NULL = 0); BWD_APPLY: k1 */
+  const float* p1;   /* BN_ACT: shift (NULL = 0); BWD_APPLY: k2 */
+  const float* p2;   /* BWD_APPLY: k3 */
+  const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y */
+} maai_conv_epilogue;
+int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
+                            const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);
+
 /* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):
  *   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]
  * dw is fp32 [Cout][KH][KW][Cin] and must be zeroed by the caller (split-K

@@ -63,9 +63,16 @@ struct ConvArgs {
   int ostr, ooh, oow;
   int accumulate;
   int nMB, nNB;
+  // fused epilogues (maai_conv_epilogue): 0 store, 1 statistics only, 2 BN-apply(+residual)(+ReLU),
+  // 3 BN-backward reduce (partials of dz and dz*(y-mean)), 4 BN-backward apply (k1*dz - k2 - k3*y)
+  int emode, erelu;
+  const float* ep0;
+  const float* ep1;
+  const float* ep2;
+  const void* et;
 };
 
-template <typename T, int BM, int BN, int NSTAGE>
+template <typename T, int BM, int BN, int NSTAGE, int EMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
@@ -193,7 +200,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
   float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm][2][BN]
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (EMODE == 1) {
+    // statistics only: the accumulators never leave the registers
+  } else if constexpr (sizeof(T) == 2) {
     // Each lane holds 4 rows x 1 column per 16x16 tile.  Lane pairs (l, l^1) swap halves through DPP so that
     // the even lane owns rows 0,1 and the odd lane rows 2,3 of a 2-column strip: two packed ds_write_b32 per
     // tile instead of four ds_write_b16, conflict-free within each 32-lane half (row pitch 272 B).
@@ -226,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
         }
   }
-  if (a.stats) {
+  const bool fstats = a.stats && EMODE != 3;
+  if (fstats) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = 0.f, q = 0.f;
@@ -249,13 +259,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
-  if (a.stats && tid < 2 * BN) {
+  if (fstats && tid < 2 * BN) {
     const int which = tid / BN, c = tid - which * BN;
     a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
   }
+  if constexpr (EMODE == 1) return;
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
   constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
+  constexpr int NV = Vec16<T>::N;
   const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
+  const int chf = tid % CPR;                 // this thread's chunk column (256 % CPR == 0)
+  const int cbase = nb * BN + chf * EPC;     // its first output channel
+  constexpr int NQ = EMODE >= 2 ? NV : 1;    // per-channel epilogue parameters live only in the fused kernels
+  float q0[NQ], q1[NQ], q2[NQ], s1[NQ], s2[NQ];
+  if constexpr (EMODE >= 2) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      q0[e] = a.ep0 ? a.ep0[cbase + e] : (EMODE == 2 ? 1.f : 0.f);
+      q1[e] = ((EMODE == 2 || EMODE == 4) && a.ep1) ? a.ep1[cbase + e] : 0.f;
+      q2[e] = (EMODE == 4 && a.ep2) ? a.ep2[cbase + e] : 0.f;
+      s1[e] = 0.f;
+      s2[e] = 0.f;
+    }
+  }
 #pragma unroll 2
   for (int idx = tid; idx < BM * CPR; idx += 256) {
     const int row = idx / CPR, ch = idx - row * CPR;
@@ -273,47 +299,133 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     T* dst = y + ooff;
     Vec16<T> v;
     v.load(ct + row * LDC + ch * EPC);
+    if constexpr (EMODE >= 2) {
+      float fv[NV];
+      v.get(fv);
+      if constexpr (EMODE == 2) {  // out = act(y*scale + shift (+ residual))
+#pragma unroll
+        for (int e = 0; e < NV; ++e) fv[e] = fv[e] * q0[e] + q1[e];
+        if (a.et) {
+          Vec16<T> r;
+          r.load(reinterpret_cast<const T*>(a.et) + ooff);
+          float fr[NV];
+          r.get(fr);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) fv[e] += fr[e];
+        }
+        if (a.erelu) {
+#pragma unroll
+          for (int e = 0; e < NV; ++e) fv[e] = fmaxf(fv[e], 0.f);
+        }
+        v.set(fv);
+        v.store(dst);
+      } else {
+        Vec16<T> dzv;
+        dzv.load(reinterpret_cast<const T*>(a.et) + ooff);
+        float dz[NV];
+        dzv.get(dz);
+        if constexpr (EMODE == 3) {  // sums of dz and dz*(y-mean)
+#pragma unroll
+          for (int e = 0; e < NV; ++e) {
+            s1[e] += dz[e];
+            s2[e] += dz[e] * (fv[e] - q0[e]);
+          }
+        } else {  // dy = k1*dz - k2 - k3*y
+#pragma unroll
+          for (int e = 0; e < NV; ++e) fv[e] = q0[e] * dz[e] - q1[e] - q2[e] * fv[e];
+          v.set(fv);
+          v.store(dst);
+        }
+      }
+      continue;
+    }
     if (a.accumulate || a.mask) {
-      float fv[Vec16<T>::N];
+      float fv[NV];
       v.get(fv);
       if (a.accumulate) {
         Vec16<T> o;
         o.load(dst);
-        float fo[Vec16<T>::N];
+        float fo[NV];
         o.get(fo);
 #pragma unroll
-        for (int e = 0; e < Vec16<T>::N; ++e) fv[e] += fo[e];
+        for (int e = 0; e < NV; ++e) fv[e] += fo[e];
       }
       if (a.mask) {
         Vec16<T> mk;
         mk.load(reinterpret_cast<const T*>(a.mask) + ooff);
-        float fm[Vec16<T>::N];
+        float fm[NV];
         mk.get(fm);
 #pragma unroll
-        for (int e = 0; e < Vec16<T>::N; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
+        for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
       }
       v.set(fv);
     }
     v.store(dst);
   }
+  if constexpr (EMODE == 3) {
+    // lanes l, l+CPR, l+2CPR.. of a wave hold the same channels: butterfly, then the four waves through LDS
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+        s1[e] += __shfl_xor(s1[e], o);
+        s2[e] += __shfl_xor(s2[e], o);
+      }
+    }
+    __syncthreads();  // everyone is done reading the C tile / the forward-statistics scratch
+    float* red4 = reinterpret_cast<float*>(smem);  // [4 waves][2][BN], reuses the C tile
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        red4[(wid * 2 + 0) * BN + lane * EPC + e] = s1[e];
+        red4[(wid * 2 + 1) * BN + lane * EPC + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid - which * BN;
+      a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] =
+          red4[which * BN + c] + red4[(2 + which) * BN + c] + red4[(4 + which) * BN + c] + red4[(6 + which) * BN + c];
+    }
+  }
 }
 
-template <typename T, int BM, int BN, int NSTAGE>
-static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int NSTAGE, int EMODE>
+static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int stage = NSTAGE * (BM + BN) * 64;
   constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 4 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
+}
+
+// the fused-epilogue variants are separate instantiations so that the plain kernel keeps its register budget
+// (76 VGPRs -> 3 waves/SIMD); they exist for the 128-row tile only (the fused units are pointwise layers)
+template <typename T, int BM, int BN, int NSTAGE>
+static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
+  if constexpr (BM == 128) {
+    switch (a.emode) {
+      case 1: return launch_conv_e<T, BM, BN, NSTAGE, 1>(a, st);
+      case 2: return launch_conv_e<T, BM, BN, NSTAGE, 2>(a, st);
+      case 3: return launch_conv_e<T, BM, BN, NSTAGE, 3>(a, st);
+      case 4: return launch_conv_e<T, BM, BN, NSTAGE, 4>(a, st);
+      default: break;
+    }
+  }
+  if (a.emode != 0) {
+    maai_set_error("conv2d_igemm: fused epilogues need the 128-row tile");
+    return MAAI_ERR_UNSUPPORTED;
+  }
+  return launch_conv_e<T, BM, BN, NSTAGE, 0>(a, st);
 }
 
 // ring depth by K extent: short K loops (the HBM-bound 1x1 convolutions) never fill a deep ring and are
@@ -342,7 +454,19 @@ static int choose_bm(const maai_conv_desc* d, int dtype) {
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                  const void* relu_mask, int dtype, void* stream) {
-  MAAI_CHECK_ARG(d && x && w && y, "conv2d_igemm: null pointer");
+  return maai_conv2d_igemm_fused(d, x, w, y, stats_partial, relu_mask, nullptr, dtype, stream);
+}
+
+extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
+                                       const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream) {
+  const int emode = epi ? epi->mode : MAAI_EPI_STORE;
+  MAAI_CHECK_ARG(d && x && w, "conv2d_igemm: null pointer");
+  MAAI_CHECK_ARG(emode >= 0 && emode <= 4, "conv2d_igemm: bad epilogue mode");
+  MAAI_CHECK_ARG(y || emode == MAAI_EPI_STATS_ONLY || emode == MAAI_EPI_BWD_REDUCE, "conv2d_igemm: null output");
+  MAAI_CHECK_ARG((emode != MAAI_EPI_STATS_ONLY && emode != MAAI_EPI_BWD_REDUCE) || stats_partial, "conv2d_igemm: this epilogue needs the partial-sum slab");
+  MAAI_CHECK_ARG(emode < MAAI_EPI_BWD_REDUCE || epi->t, "conv2d_igemm: BN-backward epilogues need dz");
+  MAAI_CHECK_ARG(emode != MAAI_EPI_BWD_APPLY || (epi->p0 && epi->p1 && epi->p2), "conv2d_igemm: BN-backward apply needs k1, k2, k3");
+  MAAI_CHECK_ARG(emode < 2 || (!d->accumulate && !relu_mask && d->out_stride == 1), "conv2d_igemm: fused BN epilogues are dense, non-accumulating");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_igemm: dtype must be MAAI_BF16 or MAAI_F32");
   const int bk = dtype == MAAI_BF16 ? 32 : 16;
   MAAI_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "conv2d_igemm: bad dims");
@@ -357,6 +481,12 @@ extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const v
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OHg = d->OHg; a.OWg = d->OWg;
   a.OH = d->OH; a.OW = d->OW; a.ostr = d->out_stride; a.ooh = d->out_off_h; a.oow = d->out_off_w;
   a.accumulate = d->accumulate;
+  a.emode = emode;
+  a.erelu = epi ? epi->relu : 0;
+  a.ep0 = epi ? epi->p0 : nullptr;
+  a.ep1 = epi ? epi->p1 : nullptr;
+  a.ep2 = epi ? epi->p2 : nullptr;
+  a.et = epi ? epi->t : nullptr;
   a.M = (long long)d->N * d->OHg * d->OWg;
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
   const int bm = choose_bm(d, dtype);

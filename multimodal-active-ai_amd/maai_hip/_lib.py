@@ -24,7 +24,14 @@ class ConvDesc(C.Structure):
                                    "OH", "OW", "out_stride", "out_off_h", "out_off_w", "accumulate")]
 
 
+class ConvEpilogue(C.Structure):
+    """maai_conv_epilogue"""
+    _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p)]
+
+
+EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY = range(5)
 _P_DESC = C.POINTER(ConvDesc)
+_P_EPI = C.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); mirrors include/maai_hip.h line by line
 SIGNATURES = {
@@ -33,6 +40,7 @@ SIGNATURES = {
     "maai_device_count": (c_i, []),
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
+    "maai_conv2d_igemm_fused": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, _P_EPI, c_i, c_p]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),

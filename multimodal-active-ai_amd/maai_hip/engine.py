@@ -154,7 +154,22 @@ def w_linear_dgrad(param, dtype, nhwc_from=None):
 # ----------------------------------------------------------------------------
 class _Rec(object):
     __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
-                 "count", "world", "training", "form", "in_hw")
+                 "count", "world", "training", "form", "in_hw", "fused")
+
+
+# Pointwise expanding convolutions with few input channels (conv3 / downsample of the first stages) are HBM-bound
+# on their OUTPUT: they run as a fused unit that recomputes the cheap GEMM instead of storing / re-reading the raw
+# conv output (forward: statistics-only pass + BN/residual/ReLU epilogue; backward: reduce + apply epilogues).
+# Measured on MI355X at B=256 (bench.py, MAAI_FUSE_MAX_CIN=128): the BN/ReLU passes shrink from 161 to 82 ms but the
+# extra conv passes cost 92 ms, because the short-K conv workgroups are latency-serialised (launch, load wait,
+# MFMA, epilogue) rather than streaming at the HBM rate — net -3 %.  So the fused unit is OFF by default (0) until
+# the pointwise kernel is persistent; the kernels and their bit-exactness tests stay in place.
+_FUSE = {"max_cin": int(os.environ.get("MAAI_FUSE_MAX_CIN", "0"))}
+
+
+def _fusable(conv, form):
+    return (form == "fwd" and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.in_channels <= _FUSE["max_cin"] and conv.out_channels >= 4 * conv.in_channels)
 
 
 def _sync_world(bn):
@@ -180,10 +195,17 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     training = bn.training or (bn.running_mean is None)
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
+    fused = _fusable(conv, form)
+    y = None
     if training:
-        y, part = K.conv2d(x, wq, stride, pad, pad_w, stats=True)
-        c = y.shape[-1]
-        count = y.numel() // c
+        if fused:
+            part = K.conv2d_stats_only(x, wq)
+            c = wq.shape[0]
+            count = x.numel() // x.shape[-1]
+        else:
+            y, part = K.conv2d(x, wq, stride, pad, pad_w, stats=True)
+            c = y.shape[-1]
+            count = y.numel() // c
         sums = K.reduce_partials(part)
         world = _sync_world(bn)
         if world > 1:
@@ -200,10 +222,21 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
             mom = 0.0
         mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
-        y = K.conv2d(x, wq, stride, pad, pad_w)
+        if not fused:
+            y = K.conv2d(x, wq, stride, pad, pad_w)
         scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         mean = invstd = None
-        count, world = y.numel() // y.shape[-1], 1
+        count, world = x.numel() // x.shape[-1] if fused else y.numel() // y.shape[-1], 1
+    if fused:
+        out = K.conv2d_bn_act(x, wq, scale, shift, residual, relu)
+        if not keep:
+            return out, None
+        r = _Rec()
+        r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
+        r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
+        r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
+        r.in_hw, r.fused = (x.shape[1], x.shape[2]), True
+        return out, r
     out = K.bn_act_fwd(y, scale, shift, residual, relu)
     if not keep:
         return out, None
@@ -212,6 +245,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
+    r.fused = False
     return out, r
 
 
@@ -258,8 +292,14 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
     forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way.
     Returns dx (or None); parameter gradients go to ``grads``."""
     bn = rec.bn
+    wq_f = w_fwd(rec.conv.weight, dtype) if rec.fused else None
+
+    def reduce(mean):
+        if rec.fused:   # raw conv output never stored: recompute it inside the reduction
+            return K.conv2d_bwd_reduce(rec.x, wq_f, dout, mean)
+        return K.bn_act_bwd_reduce(dout, None, rec.y, mean, False)
     if rec.training:
-        sums = K.bn_act_bwd_reduce(dout, None, rec.y, rec.mean, False)
+        sums = reduce(rec.mean)
         gamma = bn.weight
         if rec.world > 1:
             # torch SyncBatchNorm: weight/bias gradients from the LOCAL sums, dx from the all-reduced ones
@@ -270,7 +310,7 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
             dgamma, dbeta, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
     else:
         # frozen statistics: y -> y*scale + shift is a per-channel affine map
-        sums = K.bn_act_bwd_reduce(dout, None, rec.y, bn.running_mean, False)
+        sums = reduce(bn.running_mean)
         invstd = torch.rsqrt(bn.running_var + bn.eps)
         dbeta = sums[:sums.numel() // 2].float()
         dgamma = (sums[sums.numel() // 2:].float() * invstd)
@@ -279,7 +319,10 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         grads[id(bn.weight)] = dgamma
     if bn.bias is not None and bn.bias.requires_grad:
         grads[id(bn.bias)] = dbeta
-    dy, _ = K.bn_act_bwd_apply(dout, None, rec.y, k1, k2, k3, False, True, False)
+    if rec.fused:
+        dy = K.conv2d_bwd_apply(rec.x, wq_f, dout, k1, k2, k3)
+    else:
+        dy, _ = K.bn_act_bwd_apply(dout, None, rec.y, k1, k2, k3, False, True, False)
     w = rec.conv.weight
     if w.requires_grad:
         kh = 7 if rec.form == "stem_unrolled" else rec.k

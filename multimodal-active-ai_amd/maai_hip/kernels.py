@@ -10,7 +10,8 @@ import os
 
 import torch
 
-from ._lib import BF16, F32, ConvDesc, MaaiError, check, lib
+from ._lib import (BF16, EPI_BN_ACT, EPI_BWD_APPLY, EPI_BWD_REDUCE, EPI_STATS_ONLY, F32, ConvDesc, ConvEpilogue, MaaiError,
+                   check, lib)
 
 
 def _dt(t):
@@ -132,6 +133,59 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
         check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), _dt(x), _stream()),
               "maai_conv2d_igemm")
     return (out, part) if stats else out
+
+
+def _conv_fused(x, w, stride, pad_h, pad_w, mode, out, part, p0=None, p1=None, p2=None, t=None, relu=False, name="conv_igemm"):
+    d = make_desc(x, w, stride, pad_h, pad_w)
+    epi = ConvEpilogue(mode, 1 if relu else 0, None if p0 is None else p0.data_ptr(), None if p1 is None else p1.data_ptr(),
+                       None if p2 is None else p2.data_ptr(), None if t is None else t.data_ptr())
+    m = d.N * d.OHg * d.OWg
+    es = x.element_size()
+    nbytes = es * (x.numel() + w.numel() + (m * d.Cout if out is not None else 0) + (t.numel() if t is not None else 0))
+    nm = name if not DETAIL[0] else "%s[epi%d] M%d Cin%d Cout%d k%dx%d" % (name, mode, m, d.Cin, d.Cout, d.KH, d.KW)
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes):
+        check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), None, C.byref(epi), _dt(x), _stream()),
+              "maai_conv2d_igemm_fused")
+    return d
+
+
+def _stats_slab(x, w, stride, pad_h, pad_w):
+    d = make_desc(x, w, stride, pad_h, pad_w)
+    rows = lib().maai_conv2d_stats_rows(C.byref(d), _dt(x))
+    return torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device), d
+
+
+def conv2d_stats_only(x, w, stride=1, pad_h=0, pad_w=0):
+    """BatchNorm partial statistics of conv(x, w) without storing the convolution (pass 1 of the fused unit)."""
+    _gpu(x, w)
+    part, _ = _stats_slab(x, w, stride, pad_h, pad_w)
+    _conv_fused(x, w, stride, pad_h, pad_w, EPI_STATS_ONLY, None, part)
+    return part
+
+
+def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=0, pad_w=0):
+    """out = act(conv(x, w)*scale + shift (+ residual)) in the conv epilogue (pass 2 of the fused unit)."""
+    _gpu(x, w, scale, shift, residual)
+    d = make_desc(x, w, stride, pad_h, pad_w)
+    out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
+    _conv_fused(x, w, stride, pad_h, pad_w, EPI_BN_ACT, out, None, scale, shift, None, residual, relu)
+    return out
+
+
+def conv2d_bwd_reduce(x, w, dz, mean, stride=1, pad_h=0, pad_w=0):
+    """fp64 sums [2C] of dz and dz*(conv(x,w) - mean) with the convolution recomputed, never stored."""
+    _gpu(x, w, dz, mean)
+    part, _ = _stats_slab(x, w, stride, pad_h, pad_w)
+    _conv_fused(x, w, stride, pad_h, pad_w, EPI_BWD_REDUCE, None, part, mean, None, None, dz)
+    return reduce_partials(part)
+
+
+def conv2d_bwd_apply(x, w, dz, k1, k2, k3, stride=1, pad_h=0, pad_w=0):
+    """dy = k1*dz - k2 - k3*conv(x, w) with the convolution recomputed in the same kernel."""
+    _gpu(x, w, dz, k1, k2, k3)
+    dy = torch.empty_like(dz)
+    _conv_fused(x, w, stride, pad_h, pad_w, EPI_BWD_APPLY, dy, None, k1, k2, k3, dz)
+    return dy
 
 
 _WGRAD_TUNE = {}

@@ -408,3 +408,40 @@ def test_conv_relu_mask_epilogue(K, dtype):
     ref2 = base.clone().double()
     ref2[:, :, 0::2, 0::2] = (ref2[:, :, 0::2, 0::2] + F.conv2d(x.double(), wt.double(), None, 1, 1)) * (mask2[:, :, 0::2, 0::2] > 0)
     np.testing.assert_allclose(from_nhwc(out).numpy(), ref2.float().numpy(), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", [(3, 64, 15, 15, 256), (2, 128, 9, 7, 512), (1, 32, 5, 5, 64)])
+def test_conv_fused_bn_epilogues(K, case, dtype):
+    """The fused pointwise unit (stats-only pass, BN+residual+ReLU epilogue, BN-backward reduce / apply with
+    the convolution recomputed) against the unfused kernels it replaces — same roundings, so the forward must
+    agree to 1 ulp and the backward sums to fp32 re-association."""
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    res = torch.randn(n, cout, h, w, generator=g)
+    dz = torch.randn(n, cout, h, w, generator=g)
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    mean = torch.randn(cout, generator=g) * 0.1
+    k1, k2, k3 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x, wt, res, dz = rb(x), rb(wt), rb(res), rb(dz)
+    xg, wg, rg, dzg = nhwc(x, dtype), khwc(wt, dtype), nhwc(res, dtype), nhwc(dz, dtype)
+    sc, sh, mu, k1g, k2g, k3g = (t.cuda() for t in (scale, shift, mean, k1, k2, k3))
+    # unfused references built from the already-verified kernels
+    y, part = K.conv2d(xg, wg, 1, 0, 0, stats=True)
+    part2 = K.conv2d_stats_only(xg, wg)
+    assert torch.equal(part, part2)
+    out_ref = K.bn_act_fwd(y, sc, sh, rg, True)
+    out = K.conv2d_bn_act(xg, wg, sc, sh, rg, True)
+    assert torch.equal(out, out_ref)
+    out_nr = K.conv2d_bn_act(xg, wg, sc, sh, None, False)
+    assert torch.equal(out_nr, K.bn_act_fwd(y, sc, sh, None, False))
+    sums_ref = K.bn_act_bwd_reduce(dzg, None, y, mu, False).cpu()
+    sums = K.conv2d_bwd_reduce(xg, wg, dzg, mu).cpu()
+    np.testing.assert_allclose(sums.numpy(), sums_ref.numpy(), rtol=1e-4, atol=1e-3)
+    dy_ref, _ = K.bn_act_bwd_apply(dzg, None, y, k1g, k2g, k3g, False, True, False)
+    dy = K.conv2d_bwd_apply(xg, wg, dzg, k1g, k2g, k3g)
+    assert torch.equal(dy, dy_ref)
