@@ -72,7 +72,9 @@ struct ConvArgs {
   const void* et;
 };
 
-template <typename T, int BM, int BN, int NSTAGE, int EMODE>
+// EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask.
+// PW: pointwise stride-1 layer (input pixel == output pixel): no row decode, no tap loop, no bounds tests.
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   long long abase[AR];
   int ihb[AR], iwb[AR];
   const unsigned ohw = (unsigned)(a.OHg * a.OWg);
-  const bool pointwise = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.OHg == a.IH && a.OWg == a.IW);
+  constexpr bool pointwise = PW;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const long long m = (long long)mb * BM + r0 + 64 * i;
@@ -135,12 +137,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const T* zsrc = reinterpret_cast<const T*>(g_zero64);
 
   auto issue_stage = [&](int kt, int slot) {
-    const long long tapoff = ((long long)kh * a.IW + kw) * a.Cin + c0;
+    const long long tapoff = PW ? (long long)kt * BK : ((long long)kh * a.IW + kw) * a.Cin + c0;
     char* sa = smem + slot * STAGE + widu * 1024;
     char* sb = sa + BM * 64;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const bool ok = (unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW;
+      const bool ok = PW ? (ihb[i] >= 0) : ((unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW);
       const T* src = ok ? (x + abase[i] + tapoff) : zsrc;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, 0, 0);
@@ -149,10 +151,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < BR; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + (long long)kt * BK),
                                        (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
-    c0 += BK;
-    if (c0 >= a.Cin) {
-      c0 = 0;
-      if (++kw >= a.KW) { kw = 0; ++kh; }
+    if constexpr (!PW) {
+      c0 += BK;
+      if (c0 >= a.Cin) {
+        c0 = 0;
+        if (++kw >= a.KW) { kw = 0; ++kh; }
+      }
     }
   };
 
@@ -199,29 +203,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
-  float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm][2][BN]
+  float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm x 4 lane groups][2][BN]
   if constexpr (EMODE == 1) {
     // statistics only: the accumulators never leave the registers
   } else if constexpr (sizeof(T) == 2) {
-    // Each lane holds 4 rows x 1 column per 16x16 tile.  Lane pairs (l, l^1) swap halves through DPP so that
-    // the even lane owns rows 0,1 and the odd lane rows 2,3 of a 2-column strip: two packed ds_write_b32 per
-    // tile instead of four ds_write_b16, conflict-free within each 32-lane half (row pitch 272 B).
-    uint32_t* ct32 = reinterpret_cast<uint32_t*>(smem);
-    const bool odd = lane & 1;
-    const int colp = ((lane & 15) & ~1) >> 1;  // dword column inside the 16-wide tile
+    // The short-K layers are VALU-bound in this epilogue (measured: ~600 vector instructions per wave against
+    // 32 MFMAs), so the C tile is written with the fewest vector instructions: one v_cvt_pk_bf16_f32 per row
+    // pair and four 16-bit LDS stores (low half / d16_hi) per 16x16 tile — no lane exchange, no selects, and
+    // every address is one per-lane base plus a compile-time offset.
+    unsigned short* cbase = reinterpret_cast<unsigned short*>(smem) + (wm * WM + (lane >> 4) * 4) * LDC + wn * WN + (lane & 15);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const f32x4 v = acc[i][j];
-        const float t0 = lane_xor1(odd ? v[0] : v[2]);
-        const float t1 = lane_xor1(odd ? v[1] : v[3]);
-        const uint32_t p0 = odd ? pack_bf16x2(t0, v[2]) : pack_bf16x2(v[0], t0);
-        const uint32_t p1 = odd ? pack_bf16x2(t1, v[3]) : pack_bf16x2(v[1], t1);
-        const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + (odd ? 2 : 0);
-        const int nd = (wn * WN + j * 16) / 2 + colp;
-        ct32[ml * (LDC / 2) + nd] = p0;
-        ct32[(ml + 1) * (LDC / 2) + nd] = p1;
+        const uint32_t p01 = pack_bf16x2(v[0], v[1]);
+        const uint32_t p23 = pack_bf16x2(v[2], v[3]);
+        unsigned short* c = cbase + i * 16 * LDC + j * 16;
+        c[0] = (unsigned short)p01;
+        c[LDC] = (unsigned short)(p01 >> 16);
+        c[2 * LDC] = (unsigned short)p23;
+        c[3 * LDC] = (unsigned short)(p23 >> 16);
       }
   } else {
 #pragma unroll
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
   const bool fstats = a.stats && EMODE != 3;
   if (fstats) {
+    // per lane: column n = j*16 + (lane&15), rows of its lane group; the 8 (wm, lane-group) partials per column
+    // meet in LDS (cheaper than 16 cross-row shuffles per wave)
+    float* sred = red + ((wm * 4 + (lane >> 4)) * 2) * BN + wn * WN + (lane & 15);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = 0.f, q = 0.f;
@@ -246,22 +251,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int r = 0; r < 4; ++r) {
           const float v = acc[i][j][r];
           s += v;
-          q += v * v;
+          q = __builtin_fmaf(v, v, q);
         }
-      s += __shfl_xor(s, 16);
-      q += __shfl_xor(q, 16);
-      s += __shfl_xor(s, 32);
-      q += __shfl_xor(q, 32);
-      if (lane < 16) {
-        red[(wm * 2 + 0) * BN + wn * WN + j * 16 + lane] = s;
-        red[(wm * 2 + 1) * BN + wn * WN + j * 16 + lane] = q;
-      }
+      sred[j * 16] = s;
+      sred[BN + j * 16] = q;
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (fstats && tid < 2 * BN) {
     const int which = tid / BN, c = tid - which * BN;
-    a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[(k * 2 + which) * BN + c];
+    a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
   }
   if constexpr (EMODE == 1) return;
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
@@ -270,9 +273,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
   const int chf = tid % CPR;                 // this thread's chunk column (256 % CPR == 0)
   const int cbase = nb * BN + chf * EPC;     // its first output channel
-  constexpr int NQ = EMODE >= 2 ? NV : 1;    // per-channel epilogue parameters live only in the fused kernels
+  constexpr bool FUSED = EMODE >= 2 && EMODE <= 4;  // (EMODE 5 = accumulate / mask store, not a BN epilogue)
+  constexpr int NQ = FUSED ? NV : 1;         // per-channel epilogue parameters live only in the fused kernels
   float q0[NQ], q1[NQ], q2[NQ], s1[NQ], s2[NQ];
-  if constexpr (EMODE >= 2) {
+  if constexpr (FUSED) {
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
       q0[e] = a.ep0 ? a.ep0[cbase + e] : (EMODE == 2 ? 1.f : 0.f);
@@ -282,24 +286,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       s2[e] = 0.f;
     }
   }
-#pragma unroll 2
-  for (int idx = tid; idx < BM * CPR; idx += 256) {
-    const int row = idx / CPR, ch = idx - row * CPR;
-    const long long m = (long long)mb * BM + row;
-    if (m >= a.M) continue;
-    long long opix = m;
-    if (!dense) {
-      const unsigned mu = (unsigned)m;
-      const unsigned n = mu / ohw;
-      const unsigned rem = mu - n * ohw;
-      const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
-      opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
+  constexpr int RPI = 256 / CPR;             // tile rows covered per iteration
+  const bool full = dense && ((long long)(mb + 1) * BM <= a.M);
+  const long long off0 = ((long long)mb * BM + tid / CPR) * a.Cout + nb * BN + chf * EPC;
+  const long long ostep = (long long)RPI * a.Cout;
+#pragma unroll
+  for (int it = 0; it < BM / RPI; ++it) {
+    const int row = tid / CPR + it * RPI, ch = chf;
+    long long opix;
+    long long ooff_fast = off0 + it * ostep;
+    if (!full) {
+      const long long m = (long long)mb * BM + row;
+      if (m >= a.M) continue;
+      opix = m;
+      if (!dense) {
+        const unsigned mu = (unsigned)m;
+        const unsigned n = mu / ohw;
+        const unsigned rem = mu - n * ohw;
+        const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
+        opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
+      }
+      ooff_fast = opix * a.Cout + nb * BN + ch * EPC;
     }
-    const long long ooff = opix * a.Cout + nb * BN + ch * EPC;
+    const long long ooff = ooff_fast;
     T* dst = y + ooff;
     Vec16<T> v;
     v.load(ct + row * LDC + ch * EPC);
-    if constexpr (EMODE >= 2) {
+    if constexpr (FUSED) {
       float fv[NV];
       v.get(fv);
       if constexpr (EMODE == 2) {  // out = act(y*scale + shift (+ residual))
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
       continue;
     }
-    if (a.accumulate || a.mask) {
+    if constexpr (EMODE == 5) {
       float fv[NV];
       v.get(fv);
       if (a.accumulate) {
@@ -390,22 +403,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int EMODE>
-static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
+static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int stage = NSTAGE * (BM + BN) * 64;
-  constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 4 * BN * (int)sizeof(float);
+  constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 16 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
+}
+
+template <typename T, int BM, int BN, int NSTAGE, int EMODE>
+static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
+  const bool pw = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.OHg == a.IH && a.OWg == a.IW);
+  if constexpr (EMODE >= 1 && EMODE <= 4) {
+    if (!pw) {
+      maai_set_error("conv2d_igemm: fused epilogues are for pointwise stride-1 layers");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    return launch_conv_p<T, BM, BN, NSTAGE, EMODE, true>(a, st);
+  } else {
+    return pw ? launch_conv_p<T, BM, BN, NSTAGE, EMODE, true>(a, st) : launch_conv_p<T, BM, BN, NSTAGE, EMODE, false>(a, st);
+  }
 }
 
 // the fused-epilogue variants are separate instantiations so that the plain kernel keeps its register budget
@@ -425,6 +452,7 @@ static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
     maai_set_error("conv2d_igemm: fused epilogues need the 128-row tile");
     return MAAI_ERR_UNSUPPORTED;
   }
+  if (a.accumulate || a.mask) return launch_conv_e<T, BM, BN, NSTAGE, 5>(a, st);
   return launch_conv_e<T, BM, BN, NSTAGE, 0>(a, st);
 }
 
@@ -492,7 +520,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   const int bm = choose_bm(d, dtype);
   a.nMB = (int)((a.M + bm - 1) / bm);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool n128 = d->Cout % 128 == 0;
+  static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
+  const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);
   if (dtype == MAAI_BF16) {
     if (bm == 64) return n128 ? launch_conv<bf16_t, 64, 128>(a, st) : launch_conv<bf16_t, 64, 64>(a, st);
