@@ -24,6 +24,7 @@
 // partials for BatchNorm (one deterministic slab row per M-block, no atomics).
 #include "common.h"
 #include "maai_internal.h"
+#include "conv_pw.h"
 #include <stdlib.h>
 
 template <typename T> struct Mma;
@@ -517,9 +518,23 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.et = epi ? epi->t : nullptr;
   a.M = (long long)d->N * d->OHg * d->OWg;
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // Pointwise stride-1 layers with a dense output CAN go to the direct-epilogue kernel (conv_pw.hip).  Measured
+  // on MI355X (bench.py, B = 256): 589.8 vs 596.2 images/s plain, 581.0 vs 576.8 with the fused conv+BN units —
+  // the LDS-transposed full-row stores of this file beat its 64-byte-per-pixel direct stores once the epilogue
+  // VALU diet was in, so it is opt-in (MAAI_PW_DIRECT=1, read per call so tests can toggle it).
+  const bool pw_direct = getenv("MAAI_PW_DIRECT") && atoi(getenv("MAAI_PW_DIRECT")) == 1;
+  const bool pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH &&
+                  d->OWg == d->IW && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->OH == d->OHg &&
+                  d->OW == d->OWg;
+  if (pw && pw_direct && dtype == MAAI_BF16 && choose_bm(d, dtype) == 128) {
+    PwArgs p;
+    p.x = x; p.w = w; p.y = y; p.stats = stats_partial; p.mask = relu_mask; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
+    return maai_pw_conv_launch(p, emode, st);
+  }
   const int bm = choose_bm(d, dtype);
   a.nMB = (int)((a.M + bm - 1) / bm);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
   const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);

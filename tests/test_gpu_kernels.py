@@ -410,9 +410,42 @@ def test_conv_relu_mask_epilogue(K, dtype):
     np.testing.assert_allclose(from_nhwc(out).numpy(), ref2.float().numpy(), **tol(dtype))
 
 
+@pytest.fixture(params=["0", "1"], ids=["lds-epilogue", "direct-epilogue"])
+def pw_direct(request):
+    """Both pointwise kernels: conv_fwd.hip (default) and the opt-in direct-epilogue conv_pw.hip."""
+    old = os.environ.get("MAAI_PW_DIRECT")
+    os.environ["MAAI_PW_DIRECT"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("MAAI_PW_DIRECT", None)
+    else:
+        os.environ["MAAI_PW_DIRECT"] = old
+
+
+@pytest.mark.parametrize("case", [(2, 64, 30, 30, 256), (3, 256, 15, 15, 64), (1, 512, 4, 4, 2048), (5, 96, 9, 7, 192)])
+def test_pointwise_kernels_agree(K, case, pw_direct):
+    """1x1 layers through either kernel: forward + statistics, and accumulate + ReLU-mask store."""
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    base = rb(torch.randn(n, cout, h, w, generator=g))
+    mask = rb(torch.randn(n, cout, h, w, generator=g))
+    ref = F.conv2d(x.double(), wt.double())
+    y, part = K.conv2d(nhwc(x, torch.bfloat16), khwc(wt, torch.bfloat16), 1, 0, 0, stats=True)
+    np.testing.assert_allclose(from_nhwc(y).numpy(), ref.float().numpy(), **tol(torch.bfloat16))
+    sums = K.reduce_partials(part).cpu()
+    np.testing.assert_allclose(sums[:cout].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=2e-3 * (n * h * w) ** 0.5)
+    np.testing.assert_allclose(sums[cout:].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=1e-3)
+    out = nhwc(base, torch.bfloat16)
+    K.conv2d(nhwc(x, torch.bfloat16), khwc(wt, torch.bfloat16), 1, 0, 0, out=out, accumulate=True, relu_mask=nhwc(mask, torch.bfloat16))
+    ref2 = (rb(ref.float()).double() + base.double()) * (mask > 0)
+    np.testing.assert_allclose(from_nhwc(out).numpy(), ref2.float().numpy(), **tol(torch.bfloat16))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("case", [(3, 64, 15, 15, 256), (2, 128, 9, 7, 512), (1, 32, 5, 5, 64)])
-def test_conv_fused_bn_epilogues(K, case, dtype):
+def test_conv_fused_bn_epilogues(K, case, dtype, pw_direct):
     """The fused pointwise unit (stats-only pass, BN+residual+ReLU epilogue, BN-backward reduce / apply with
     the convolution recomputed) against the unfused kernels it replaces — same roundings, so the forward must
     agree to 1 ulp and the backward sums to fp32 re-association."""
