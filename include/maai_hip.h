@@ -204,6 +204,14 @@ int maai_augment_view_u8(const void* images, const float* params, int B, int H, 
 int maai_augment_params(float* params, int B, int H, int W, unsigned long long seed, int view, float min_area,
                         float brightness, float contrast, float saturation, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Foveated retinal processor: the whole DALI graph of NVIDIA_DALI_Pipelines.py:444-480
+ * (RandomResizedCrop 640 -> Rotate -> GridMask -> noise -> Flip -> ColorTwist -> crops 400/240/100/30 ->
+ * resize 30x30) as ONE kernel.  images [B,H,W,3] u8 (padded batch; per-sample extents in params),
+ * params [B][32] f32 (layout in csrc/foveate.hip), out [4][B][OS][OS][3] u8 (view-major).
+ * ------------------------------------------------------------------------ */
+int maai_foveate_views_u8(const void* images, const float* params, int B, int H, int W, int OS, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

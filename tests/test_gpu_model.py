@@ -297,3 +297,46 @@ def test_sgd_and_lars_optimizers_step(mods):
         class B:
             optimizer, lr, momentum, weight_decay = "adagrad", 1e-3, 0.9, 0.0
         mods["Model_Util"].get_optimizer(m, B)
+
+
+def test_linear_probe_flow_on_frozen_backbone(mods, tmp_path):
+    """the consumer of the checkpoint (Representation_Evaluation.py:406-420,598-712): save_checkpoint ->
+    torch.load -> strict load_state_dict -> model.g = Identity -> eval-mode features (running statistics) -> a
+    LogisticRegression probe trained with CE on the frozen features."""
+    sys.path.append(os.path.join(SIM, "MLR"))
+    import multivariateLogisticRegression as mlr
+    B = 8
+    views = [_u8(50 + k, (B, 30, 30, 3)).cuda() for k in range(4)]
+    m = _build(mods, "resnet18", 4, 512 * 16, B, (30, 30), 0.25)
+    m.train()
+    with torch.no_grad():
+        m(views)                                     # one train-mode pass so the running statistics moved
+    path = str(tmp_path / "checkpoint.pth.tar")
+    mods["Model_Util"].save_checkpoint(dict(epoch=1, state_dict=m.state_dict(), best_prec1=0.0), False, path, str(tmp_path / "best.pth.tar"))
+    m2 = _build(mods, "resnet18", 4, 512 * 16, B, (30, 30), 1.0)
+    m2.load_state_dict(torch.load(path)["state_dict"], strict=True)
+    m2.g = mods["Model_Util"].Identity()
+    m2.eval()
+    for p in m2.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        feats = m2(views)
+    assert feats.shape == (B, 512, 4, 4)
+    # the oracle's eval-mode backbone on the same weights / buffers
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = O.backbone_forward(sd, O.pack_views([v.cpu() for v in views], B, (30, 30)), "resnet18", training=False, storage="bf16")
+    cos = torch.nn.functional.cosine_similarity(feats.cpu().flatten(1), ref.flatten(1), dim=1)
+    assert cos.min() > 0.99
+    probe = mlr.LogisticRegression(512 * 16, 10).cuda()
+    opt = torch.optim.SGD(probe.parameters(), lr=0.5)
+    y = torch.arange(B, device="cuda") % 10
+    fx = feats.flatten(1)
+    fx = fx / fx.norm(dim=1, keepdim=True)
+    l0 = None
+    for _ in range(20):
+        loss = torch.nn.functional.cross_entropy(probe(fx), y)
+        l0 = l0 if l0 is not None else loss.item()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert loss.item() < l0
