@@ -72,19 +72,30 @@ long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
  * -> relu):  forward = STATS_ONLY pass (no store) + BN_ACT pass (out = act(y*scale + shift (+ residual)));
  * backward = BWD_REDUCE pass (partial sums of dz and dz*(y-mean), same slab format as stats_partial) +
  * BWD_APPLY pass (dy = k1*dz - k2 - k3*y).  y is the bf16/f32-rounded accumulator, exactly the value the
- * unfused path would have stored. */
+ * unfused path would have stored.
+ *
+ * DGRAD_REDUCE serves the data-gradient convolutions (any kernel size, scatter and accumulate allowed): the value
+ * g this launch stores — conv (+ previous content when d->accumulate) times the ReLU mask — is the gradient dz
+ * entering the BatchNorm of the layer below (resnet.py:101-104,121-128: conv -> bn -> relu), so the BN-backward
+ * partial sums of g and g*(t - p0) (t = that layer's raw conv output, p0 = its batch mean) are reduced here,
+ * from the rounded value being stored, instead of by a separate maai_bn_act_bwd_reduce pass over dz and t.  The
+ * mask is relu_mask > 0 when relu_mask is given, else (t*p1 + p2 > 0) when p1 and p2 are given (the forward
+ * scale/shift of that BatchNorm: its ReLU output is positive exactly there, so the mask tensor need not be read),
+ * else none.  stats_partial receives maai_conv2d_stats_rows(d) rows of [2][Cout]. */
 #define MAAI_EPI_STORE 0
 #define MAAI_EPI_STATS_ONLY 1
 #define MAAI_EPI_BN_ACT 2
 #define MAAI_EPI_BWD_REDUCE 3
 #define MAAI_EPI_BWD_APPLY 4
+#define MAAI_EPI_DGRAD_REDUCE 5
 typedef struct {
   int mode;
   int relu;          /* BN_ACT: apply max(.,0) */
-  const float* p0;   /* BN_ACT: scale (NULL = 1); BWD_REDUCE: mean (NULL = 0); BWD_APPLY: k1 */
-  const float* p1;   /* BN_ACT: shift (NULL = 0); BWD_APPLY: k2 */
-  const float* p2;   /* BWD_APPLY: k3 */
-  const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y */
+  const float* p0;   /* BN_ACT: scale (NULL = 1); BWD_REDUCE, DGRAD_REDUCE: mean (NULL = 0); BWD_APPLY: k1 */
+  const float* p1;   /* BN_ACT: shift (NULL = 0); BWD_APPLY: k2; DGRAD_REDUCE: scale of the mask (nullable) */
+  const float* p2;   /* BWD_APPLY: k3; DGRAD_REDUCE: shift of the mask (nullable) */
+  const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y;
+                        DGRAD_REDUCE: the lower layer's raw conv output, laid out like y */
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);

@@ -73,13 +73,15 @@ struct ConvArgs {
   const void* et;
 };
 
-// EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask.
+// EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
+// 6 = 5 plus the BN-backward partial sums of the stored gradient (MAAI_EPI_DGRAD_REDUCE).
 // PW: pointwise stride-1 layer (input pixel == output pixel): no row decode, no tap loop, no bounds tests.
 template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, BM == 256 ? 2 : 1) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int AR = BM / 64, BR = BN / 64;  // rows staged per thread
   constexpr int STAGE = (BM + BN) * 64;      // bytes per buffer
   constexpr int LDC = BN + EPC;              // C-tile row pitch (elements), 16-B padded
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WGN, wn = wid % WGN;
   const int logical = xcd_remap(blockIdx.x, a.nMB * a.nNB);
   const int mb = logical / a.nNB, nb = logical - mb * a.nNB;
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
@@ -204,7 +206,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
-  float* red = reinterpret_cast<float*>(smem + BM * LDC * (int)sizeof(T));  // [2 wm x 4 lane groups][2][BN]
+  constexpr int CROWS = 128;                // the C tile holds 128 rows; 256-row tiles drain in two phases
+  constexpr int NPH = BM / CROWS > 0 ? (BM + CROWS - 1) / CROWS : 1;
+  float* red = reinterpret_cast<float*>(smem + (BM < CROWS ? BM : CROWS) * LDC * (int)sizeof(T));  // [WGM wm x 4 lane groups][2][BN]
+  T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
+  constexpr int NV = Vec16<T>::N;
+  const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
+  const int chf = tid % CPR;                 // this thread's chunk column (256 % CPR == 0)
+  const int cch0 = nb * BN + chf * EPC;      // its first output channel
+  constexpr bool FUSED = EMODE >= 2 && EMODE <= 4;  // (EMODE 5 = accumulate / mask store, not a BN epilogue)
+  constexpr bool PARAMS = FUSED || EMODE == 6;
+  constexpr int NQ = PARAMS ? NV : 1;        // per-channel epilogue parameters live only in the fused kernels
+  float q0[NQ], q1[NQ], q2[NQ], s1[NQ], s2[NQ];
+  if constexpr (PARAMS) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      q0[e] = a.ep0 ? a.ep0[cch0 + e] : (EMODE == 2 ? 1.f : 0.f);
+      q1[e] = ((EMODE == 2 || EMODE == 4 || EMODE == 6) && a.ep1) ? a.ep1[cch0 + e] : 0.f;
+      q2[e] = ((EMODE == 4 || EMODE == 6) && a.ep2) ? a.ep2[cch0 + e] : 0.f;
+      s1[e] = 0.f;
+      s2[e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int ph = 0; ph < NPH; ++ph) {
+  if (ph > 0) __syncthreads();  // the previous phase's readers are done with the C tile
   if constexpr (EMODE == 1) {
     // statistics only: the accumulators never leave the registers
   } else if constexpr (sizeof(T) == 2) {
@@ -212,20 +239,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // 32 MFMAs), so the C tile is written with the fewest vector instructions: one v_cvt_pk_bf16_f32 per row
     // pair and four 16-bit LDS stores (low half / d16_hi) per 16x16 tile — no lane exchange, no selects, and
     // every address is one per-lane base plus a compile-time offset.
-    unsigned short* cbase = reinterpret_cast<unsigned short*>(smem) + (wm * WM + (lane >> 4) * 4) * LDC + wn * WN + (lane & 15);
+    unsigned short* cbase = reinterpret_cast<unsigned short*>(smem) + ((wm * WM) % CROWS + (lane >> 4) * 4) * LDC + wn * WN + (lane & 15);
+    if (NPH == 1 || (wm * WM) / CROWS == ph) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const f32x4 v = acc[i][j];
-        const uint32_t p01 = pack_bf16x2(v[0], v[1]);
-        const uint32_t p23 = pack_bf16x2(v[2], v[3]);
-        unsigned short* c = cbase + i * 16 * LDC + j * 16;
-        c[0] = (unsigned short)p01;
-        c[LDC] = (unsigned short)(p01 >> 16);
-        c[2 * LDC] = (unsigned short)p23;
-        c[3 * LDC] = (unsigned short)(p23 >> 16);
-      }
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 v = acc[i][j];
+          const uint32_t p01 = pack_bf16x2(v[0], v[1]);
+          const uint32_t p23 = pack_bf16x2(v[2], v[3]);
+          unsigned short* c = cbase + i * 16 * LDC + j * 16;
+          c[0] = (unsigned short)p01;
+          c[LDC] = (unsigned short)(p01 >> 16);
+          c[2 * LDC] = (unsigned short)p23;
+          c[3 * LDC] = (unsigned short)(p23 >> 16);
+        }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -233,12 +262,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ml = wm * WM + i * 16 + (lane >> 4) * 4 + r;
+          const int ml = (wm * WM) % CROWS + i * 16 + (lane >> 4) * 4 + r;
+          if (NPH > 1 && (wm * WM) / CROWS != ph) continue;
           const int nl = wn * WN + j * 16 + (lane & 15);
           Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
         }
   }
-  const bool fstats = a.stats && EMODE != 3;
+  const bool fstats = a.stats && EMODE != 3 && EMODE != 6 && ph == 0;
   if (fstats) {
     // per lane: column n = j*16 + (lane&15), rows of its lane group; the 8 (wm, lane-group) partials per column
     // meet in LDS (cheaper than 16 cross-row shuffles per wave)
@@ -264,40 +294,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int which = tid / BN, c = tid - which * BN;
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[(k * 2 + which) * BN + c];
+    for (int k = 0; k < 4 * WGM; ++k) t += red[(k * 2 + which) * BN + c];
     a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
   }
   if constexpr (EMODE == 1) return;
-  T* __restrict__ y = reinterpret_cast<T*>(a.y);
-  constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
-  constexpr int NV = Vec16<T>::N;
-  const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
-  const int chf = tid % CPR;                 // this thread's chunk column (256 % CPR == 0)
-  const int cbase = nb * BN + chf * EPC;     // its first output channel
-  constexpr bool FUSED = EMODE >= 2 && EMODE <= 4;  // (EMODE 5 = accumulate / mask store, not a BN epilogue)
-  constexpr int NQ = FUSED ? NV : 1;         // per-channel epilogue parameters live only in the fused kernels
-  float q0[NQ], q1[NQ], q2[NQ], s1[NQ], s2[NQ];
-  if constexpr (FUSED) {
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-      q0[e] = a.ep0 ? a.ep0[cbase + e] : (EMODE == 2 ? 1.f : 0.f);
-      q1[e] = ((EMODE == 2 || EMODE == 4) && a.ep1) ? a.ep1[cbase + e] : 0.f;
-      q2[e] = (EMODE == 4 && a.ep2) ? a.ep2[cbase + e] : 0.f;
-      s1[e] = 0.f;
-      s2[e] = 0.f;
-    }
-  }
   constexpr int RPI = 256 / CPR;             // tile rows covered per iteration
   const bool full = dense && ((long long)(mb + 1) * BM <= a.M);
-  const long long off0 = ((long long)mb * BM + tid / CPR) * a.Cout + nb * BN + chf * EPC;
+  const long long off0 = ((long long)mb * BM + ph * CROWS + tid / CPR) * a.Cout + nb * BN + chf * EPC;
   const long long ostep = (long long)RPI * a.Cout;
 #pragma unroll
-  for (int it = 0; it < BM / RPI; ++it) {
+  for (int it = 0; it < (BM < CROWS ? BM : CROWS) / RPI; ++it) {
     const int row = tid / CPR + it * RPI, ch = chf;
     long long opix;
     long long ooff_fast = off0 + it * ostep;
     if (!full) {
-      const long long m = (long long)mb * BM + row;
+      const long long m = (long long)mb * BM + ph * CROWS + row;
       if (m >= a.M) continue;
       opix = m;
       if (!dense) {
@@ -353,6 +364,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
       continue;
     }
+    if constexpr (EMODE == 6) {
+      float fv[NV], fy[NV];
+      v.get(fv);
+      if (a.accumulate) {
+        Vec16<T> o;
+        o.load(dst);
+        float fo[NV];
+        o.get(fo);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) fv[e] += fo[e];
+      }
+      Vec16<T> yv;
+      yv.load(reinterpret_cast<const T*>(a.et) + ooff);
+      yv.get(fy);
+      if (a.mask) {
+        Vec16<T> mk;
+        mk.load(reinterpret_cast<const T*>(a.mask) + ooff);
+        float fm[NV];
+        mk.get(fm);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
+      } else if (a.ep1 && a.ep2) {  // the lower layer's ReLU output is positive exactly where y*scale + shift is
+#pragma unroll
+        for (int e = 0; e < NV; ++e) fv[e] = (fy[e] * q1[e] + q2[e]) > 0.f ? fv[e] : 0.f;
+      }
+      v.set(fv);
+      v.get(fv);  // the rounded value being stored is what a separate reduction pass would read back
+#pragma unroll
+      for (int e = 0; e < NV; ++e) {
+        s1[e] += fv[e];
+        s2[e] += fv[e] * (fy[e] - q0[e]);
+      }
+    }
     if constexpr (EMODE == 5) {
       float fv[NV];
       v.get(fv);
@@ -376,7 +420,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     v.store(dst);
   }
-  if constexpr (EMODE == 3) {
+  }  // phases
+  if constexpr (EMODE == 3 || EMODE == 6) {
     // lanes l, l+CPR, l+2CPR.. of a wave hold the same channels: butterfly, then the four waves through LDS
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -408,7 +453,7 @@ template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
 static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int stage = NSTAGE * (BM + BN) * 64;
-  constexpr int epi = BM * (BN + EPC) * (int)sizeof(T) + 16 * BN * (int)sizeof(float);
+  constexpr int epi = (BM < 128 ? BM : 128) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
@@ -449,6 +494,7 @@ static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
       default: break;
     }
   }
+  if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_conv_e<T, BM, BN, NSTAGE, 6>(a, st);
   if (a.emode != 0) {
     maai_set_error("conv2d_igemm: fused epilogues need the 128-row tile");
     return MAAI_ERR_UNSUPPORTED;
@@ -472,13 +518,22 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return launch_conv_n<T, BM, BN, 3>(a, st);
 }
 
-// M-tile: 128 rows; a 64-row variant (half the LDS / accumulator footprint, twice the resident workgroups)
-// is compiled in and selectable with MAAI_CONV_BM=64 for experiments.
+// M-tile rows.  256-row tiles for the long-K spatial layers (bf16): each wave then owns 128x64 (or 64x64 in a 4x1
+// wave column for 64-channel outputs), i.e. 6 LDS-DMA + 12 fragment reads per 32 MFMAs instead of 4 + 8 per 16 —
+// the K loop is issue-bound on exactly those (profiles/r01_pmc_conv3x3_sq.json).  Measured on MI355X
+// (scripts/conv_micro.py, B = 64): 3x3 C128@112 769 -> 803, C256@56 806 -> 877, C512@28 797 -> 912 TFLOP/s.  Not
+// for the pointwise layers (HBM-bound; their fused epilogues are 128-row only) nor for launches that would leave
+// CUs idle.  MAAI_CONV_BM = 64 | 128 | 256 overrides (read per call so the tests can toggle it); a 64-row variant
+// loses on every ResNet-50 shape.
 static int choose_bm(const maai_conv_desc* d, int dtype) {
-  static const int forced = getenv("MAAI_CONV_BM") ? atoi(getenv("MAAI_CONV_BM")) : 0;
-  if (forced == 64 || forced == 128) return forced;
-  (void)dtype;
-  return 128;  // measured (scripts/conv_micro.py, MAAI_CONV_BM=64): 64-row tiles lose on every ResNet-50 shape
+  const char* e = getenv("MAAI_CONV_BM");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 64) return 64;
+  if (forced == 128 || dtype != MAAI_BF16 || d->KH * d->KW == 1) return 128;
+  if (forced == 256) return 256;
+  const long long M = (long long)d->N * d->OHg * d->OWg;
+  const long long tiles = ((M + 255) / 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
+  return (d->KH * d->KW * d->Cin >= 512 && tiles >= 512) ? 256 : 128;
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
@@ -490,12 +545,12 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
                                        const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream) {
   const int emode = epi ? epi->mode : MAAI_EPI_STORE;
   MAAI_CHECK_ARG(d && x && w, "conv2d_igemm: null pointer");
-  MAAI_CHECK_ARG(emode >= 0 && emode <= 4, "conv2d_igemm: bad epilogue mode");
+  MAAI_CHECK_ARG(emode >= 0 && emode <= MAAI_EPI_DGRAD_REDUCE, "conv2d_igemm: bad epilogue mode");
   MAAI_CHECK_ARG(y || emode == MAAI_EPI_STATS_ONLY || emode == MAAI_EPI_BWD_REDUCE, "conv2d_igemm: null output");
-  MAAI_CHECK_ARG((emode != MAAI_EPI_STATS_ONLY && emode != MAAI_EPI_BWD_REDUCE) || stats_partial, "conv2d_igemm: this epilogue needs the partial-sum slab");
-  MAAI_CHECK_ARG(emode < MAAI_EPI_BWD_REDUCE || epi->t, "conv2d_igemm: BN-backward epilogues need dz");
+  MAAI_CHECK_ARG((emode != MAAI_EPI_STATS_ONLY && emode != MAAI_EPI_BWD_REDUCE && emode != MAAI_EPI_DGRAD_REDUCE) || stats_partial, "conv2d_igemm: this epilogue needs the partial-sum slab");
+  MAAI_CHECK_ARG(emode < MAAI_EPI_BWD_REDUCE || epi->t, "conv2d_igemm: BN-backward epilogues need dz (DGRAD_REDUCE: the raw conv output)");
   MAAI_CHECK_ARG(emode != MAAI_EPI_BWD_APPLY || (epi->p0 && epi->p1 && epi->p2), "conv2d_igemm: BN-backward apply needs k1, k2, k3");
-  MAAI_CHECK_ARG(emode < 2 || (!d->accumulate && !relu_mask && d->out_stride == 1), "conv2d_igemm: fused BN epilogues are dense, non-accumulating");
+  MAAI_CHECK_ARG(emode < 2 || emode == MAAI_EPI_DGRAD_REDUCE || (!d->accumulate && !relu_mask && d->out_stride == 1), "conv2d_igemm: fused BN epilogues are dense, non-accumulating");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_igemm: dtype must be MAAI_BF16 or MAAI_F32");
   const int bk = dtype == MAAI_BF16 ? 32 : 16;
   MAAI_CHECK_ARG(d->N > 0 && d->IH > 0 && d->IW > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0, "conv2d_igemm: bad dims");
@@ -527,7 +582,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   const bool pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH &&
                   d->OWg == d->IW && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->OH == d->OHg &&
                   d->OW == d->OWg;
-  if (pw && pw_direct && dtype == MAAI_BF16 && choose_bm(d, dtype) == 128) {
+  if (pw && pw_direct && emode != MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && choose_bm(d, dtype) == 128) {
     PwArgs p;
     p.x = x; p.w = w; p.y = y; p.stats = stats_partial; p.mask = relu_mask; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
     p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
@@ -540,6 +595,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.nNB = d->Cout / (n128 ? 128 : 64);
   if (dtype == MAAI_BF16) {
     if (bm == 64) return n128 ? launch_conv<bf16_t, 64, 128>(a, st) : launch_conv<bf16_t, 64, 64>(a, st);
+    if (bm == 256) return n128 ? launch_conv_n<bf16_t, 256, 128, 3>(a, st) : launch_conv_n<bf16_t, 256, 64, 3>(a, st);
     return n128 ? launch_conv<bf16_t, 128, 128>(a, st) : launch_conv<bf16_t, 128, 64>(a, st);
   }
   if (bm == 64) return n128 ? launch_conv<float, 64, 128>(a, st) : launch_conv<float, 64, 64>(a, st);

@@ -29,7 +29,7 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p)]
 
 
-EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY = range(5)
+EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY, EPI_DGRAD_REDUCE = range(6)
 _P_DESC = C.POINTER(ConvDesc)
 _P_EPI = C.POINTER(ConvEpilogue)
 

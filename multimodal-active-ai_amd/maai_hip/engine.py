@@ -154,7 +154,7 @@ def w_linear_dgrad(param, dtype, nhwc_from=None):
 # ----------------------------------------------------------------------------
 class _Rec(object):
     __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
-                 "count", "world", "training", "form", "in_hw", "fused")
+                 "count", "world", "training", "form", "in_hw", "fused", "shift")
 
 
 # Pointwise expanding convolutions with few input channels (conv3 / downsample of the first stages) are HBM-bound
@@ -235,7 +235,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused = (x.shape[1], x.shape[2]), True
+        r.in_hw, r.fused, r.shift = (x.shape[1], x.shape[2]), True, shift
         return out, r
     out = K.bn_act_fwd(y, scale, shift, residual, relu)
     if not keep:
@@ -245,13 +245,25 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
-    r.fused = False
+    r.fused, r.shift = False, shift
     return out, r
 
 
-def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None):
+# The BatchNorm-backward reduction of a unit (sums of dz and dz*(y - mean)) rides the epilogue of the data-gradient
+# convolution that PRODUCES dz, instead of a separate pass that reads dz and y back (MAAI_EPI_DGRAD_REDUCE); the
+# ReLU mask of a plain conv-bn-relu unit then comes from y*scale + shift > 0, so its output is not read either.
+_DGRAD_REDUCE = {"enabled": os.environ.get("MAAI_DGRAD_REDUCE", "1") != "0"}
+
+
+def _reduce_mean(rec):
+    return rec.mean if rec.training else rec.bn.running_mean
+
+
+def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None):
     """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]; with ``relu_mask`` (= x,
-    a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue."""
+    a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue.  ``below`` = the record of
+    the unit whose output x is: the mask is then that unit's, and where every pixel of dx is written exactly once
+    the unit's BN-backward sums are reduced in the same epilogue.  Returns (dx, fp64 sums [2C] or None)."""
     n, cin = dy.shape[0], weight.shape[1]
     ih, iw = in_hw
     cls = dgrad_classes(k, stride, pad)
@@ -261,17 +273,36 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
         out = alloc((n, ih, iw, cin), dtype=dy.dtype, device=dy.device)
         if accumulate:
             raise MaaiError("conv_dgrad: accumulate needs an output tensor")
+    fuse = below is not None and _DGRAD_REDUCE["enabled"] and not empty and below.y is not None
+    from_y = False
+    if below is not None:
+        if not below.relu:
+            raise MaaiError("conv_dgrad: the unit below has no ReLU to take a mask from")
+        from_y = fuse and not below.has_res
+        relu_mask = None if from_y else below.out
+    launches = []
     for (a, khs, pad_h) in cls:
         for (b, kws, pad_w) in cls:
             if not khs or not kws:
                 continue
-            wq = w_dgrad(weight, dtype, khs, kws)
             gh, gw = (ih - a + stride - 1) // stride, (iw - b + stride - 1) // stride
             if gh <= 0 or gw <= 0:
                 continue
-            K.conv2d(dy, wq, 1, pad_h, pad_w, out=out, grid_hw=(gh, gw), out_hw=(ih, iw), out_stride=stride, out_off=(a, b),
+            launches.append((w_dgrad(weight, dtype, khs, kws), pad_h, pad_w, (gh, gw), (a, b)))
+    if not fuse:
+        for (wq, pad_h, pad_w, grid, off) in launches:
+            K.conv2d(dy, wq, 1, pad_h, pad_w, out=out, grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off,
                      accumulate=accumulate, relu_mask=relu_mask)
-    return out
+        return out, None
+    rows = [K.conv2d_stats_rows(dy, wq, 1, pad_h, pad_w, grid, (ih, iw), stride, off) for (wq, pad_h, pad_w, grid, off) in launches]
+    slab = torch.empty((sum(rows), 2, cin), dtype=torch.float32, device=dy.device)
+    r0 = 0
+    for (wq, pad_h, pad_w, grid, off), nr in zip(launches, rows):
+        K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], below.y, _reduce_mean(below),
+                              below.scale if from_y else None, below.shift if from_y else None, relu_mask,
+                              grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate)
+        r0 += nr
+    return out, K.reduce_partials(slab)
 
 
 def _grad_to_reference(rec, dw):
@@ -286,15 +317,20 @@ def _grad_to_reference(rec, dw):
     return g.contiguous()
 
 
-def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None):
+def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None, below=None,
+             presums=None):
     """Backward of unit_fwd.  CONVENTION: ``dout`` is already multiplied by the ReLU mask of this unit's
     output (the kernel that produced it folded ``* (out > 0)`` into its epilogue), so nothing here reads the
-    forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way.
-    Returns dx (or None); parameter gradients go to ``grads``."""
+    forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way;
+    ``below`` = the record of the unit that produced that input (mask AND, where possible, its BN-backward sums
+    from the same epilogue).  ``presums`` = this unit's own sums if the producer of ``dout`` already reduced them.
+    Returns (dx or None, sums for ``below`` or None); parameter gradients go to ``grads``."""
     bn = rec.bn
     wq_f = w_fwd(rec.conv.weight, dtype) if rec.fused else None
 
     def reduce(mean):
+        if presums is not None:
+            return presums
         if rec.fused:   # raw conv output never stored: recompute it inside the reduction
             return K.conv2d_bwd_reduce(rec.x, wq_f, dout, mean)
         return K.bn_act_bwd_reduce(dout, None, rec.y, mean, False)
@@ -340,11 +376,11 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         else:
             dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
             grads[id(w)] = _grad_to_reference(rec, dw)
-    dx = None
+    dx, below_sums = None, None
     if need_dx:
-        dx = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate,
-                        relu_mask=relu_mask)
-    return dx
+        dx, below_sums = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate,
+                                    relu_mask=relu_mask, below=below)
+    return dx, below_sums
 
 
 def relu_mask_grad(dout, out):
@@ -409,37 +445,50 @@ def backbone_fwd(resnet, x, dtype, keep):
     return out, tape
 
 
-def block_bwd(entry, dout, grads, dtype):
+def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
     """Backward of one residual block.  ``dout`` must already carry the block output's ReLU mask; the
     returned gradient wrt the block input carries the block input's mask (folded into the last epilogue).
-    ``dout`` may be overwritten (identity shortcut: the conv1 data gradient is accumulated into it)."""
+    ``dout`` may be overwritten (identity shortcut: the conv1 data gradient is accumulated into it).
+    ``prev`` = record of the unit that produced the block input, ``presums`` = the last unit's BN-backward sums
+    when the producer of ``dout`` reduced them.  Returns (dx, sums for ``prev`` or None)."""
     _, r1, r2, r3, rd = entry
-    d = unit_bwd(r3, dout, grads, dtype, relu_mask=r3.x)        # grad wrt the last conv's (post-ReLU) input
+    d, s = unit_bwd(r3, dout, grads, dtype, below=r2 if r2 is not None else r1, presums=presums)
     if r2 is not None:
-        d = unit_bwd(r2, d, grads, dtype, relu_mask=r2.x)
+        d, s = unit_bwd(r2, d, grads, dtype, below=r1, presums=s)
     if rd is not None:
         # dx = dgrad(conv1) (dense) then += dgrad(downsample) (strided scatter, accumulate + mask epilogue)
         # (mask both: pixels the strided scatter never touches keep the first, already masked, value;
-        #  m*(m*a + b) == m*(a + b) for a 0/1 mask)
-        dx = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x)
-        dx = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x)
+        #  m*(m*a + b) == m*(a + b) for a 0/1 mask).  The sums for ``prev`` can only ride the second pass, and
+        #  only if it rewrites every pixel (stride-1 downsample); otherwise ``prev`` reduces them itself.
+        dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x, presums=s)
+        if prev is not None:
+            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev)
+        else:
+            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x)
     else:
         # identity shortcut: dx = dout + dgrad(conv1), accumulated in place in the conv epilogue
-        dx = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, relu_mask=r1.x)
-    return dx
+        if prev is not None:
+            dx, sp = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, below=prev, presums=s)
+        else:
+            dx, sp = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, relu_mask=r1.x, presums=s)
+    return dx, sp
 
 
 def backbone_bwd(tape, dout, grads, dtype):
     """``dout``: gradient wrt the layer4 map, NOT yet masked."""
     dout = relu_mask_grad(dout, tape[-1][3].out if tape[-1][0] == "block" else tape[-1][1].out)
-    for entry in reversed(tape):
+    sums = None
+    for i in range(len(tape) - 1, -1, -1):
+        entry = tape[i]
         if entry[0] == "stem":
             r = entry[1]
             K.FLOPS_SCALE[0] = (49.0 * r.conv.weight.shape[1]) / ((7 if r.form == "stem_unrolled" else 49) * r.x.shape[-1])
-            unit_bwd(r, dout, grads, dtype, need_dx=False)
+            unit_bwd(r, dout, grads, dtype, need_dx=False, presums=sums)
             K.FLOPS_SCALE[0] = 1.0
             return
-        dout = block_bwd(entry, dout, grads, dtype)
+        below = tape[i - 1]
+        prev = below[1] if below[0] == "stem" else below[3]
+        dout, sums = block_bwd(entry, dout, grads, dtype, prev=prev, presums=sums)
 
 
 # ----------------------------------------------------------------------------

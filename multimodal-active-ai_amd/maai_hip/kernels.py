@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from ._lib import (BF16, EPI_BN_ACT, EPI_BWD_APPLY, EPI_BWD_REDUCE, EPI_STATS_ONLY, F32, ConvDesc, ConvEpilogue, MaaiError,
+from ._lib import (BF16, EPI_BN_ACT, EPI_BWD_APPLY, EPI_BWD_REDUCE, EPI_DGRAD_REDUCE, EPI_STATS_ONLY, F32, ConvDesc, ConvEpilogue, MaaiError,
                    check, lib)
 
 
@@ -133,6 +133,38 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
         check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), _dt(x), _stream()),
               "maai_conv2d_igemm")
     return (out, part) if stats else out
+
+
+def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0)):
+    """Rows of the partial-sum slab one conv2d launch of this geometry writes."""
+    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, False)
+    return int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
+
+
+def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
+                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False):
+    """conv2d(..., out=out) for a data gradient whose epilogue also reduces the BatchNorm-backward partial sums of
+    the stored values g: rows of ``part`` [rows,2,Cout] get sum(g) and sum(g*(lower_y - mean)).  The ReLU mask is
+    ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE)."""
+    _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask)
+    if x.dtype != w.dtype or lower_y.dtype != out.dtype or lower_y.shape != out.shape:
+        raise MaaiError("conv2d_store_reduce: operand dtype / shape mismatch")
+    if relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
+        raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
+    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
+    rows = int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
+    if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != (rows, 2, d.Cout):
+        raise MaaiError("conv2d_store_reduce: partial slab must be fp32 [%d, 2, %d]" % (rows, d.Cout))
+    epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
+                       None if shift is None else shift.data_ptr(), lower_y.data_ptr())
+    m = d.N * d.OHg * d.OWg
+    es = x.element_size()
+    nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[red] M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
+                es * (x.numel() + w.numel() + m * d.Cout * (2 + (1 if accumulate else 0) + (1 if relu_mask is not None else 0)))):
+        check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
+              "maai_conv2d_igemm_fused")
+    return out
 
 
 def _conv_fused(x, w, stride, pad_h, pad_w, mode, out, part, p0=None, p1=None, p2=None, t=None, relu=False, name="conv_igemm"):

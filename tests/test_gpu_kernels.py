@@ -57,9 +57,22 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["128", "256"])
+def conv_bm(request):
+    """Row count of the implicit-GEMM tile (256-row tiles are normally chosen by shape; forced here so the small
+    parity cases cover them, including the two-phase C-tile drain and the 4x1 wave column for 64-channel outputs)."""
+    old = os.environ.get("MAAI_CONV_BM")
+    os.environ["MAAI_CONV_BM"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("MAAI_CONV_BM", None)
+    else:
+        os.environ["MAAI_CONV_BM"] = old
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_and_stats(K, case, dtype):
+def test_conv_fwd_and_stats(K, case, dtype, conv_bm):
     n, cin, h, w, cout, k, s, p = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -78,7 +91,7 @@ def test_conv_fwd_and_stats(K, case, dtype):
     np.testing.assert_allclose(sums[cout:].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=1e-3)
 
 
-def test_conv_exact_integer_layout(K):
+def test_conv_exact_integer_layout(K, conv_bm):
     """Integer-valued operands: every product and sum is exact in bf16/fp32, so any
     fragment-layout or swizzle mistake shows as a hard mismatch (asymmetric data)."""
     g = torch.Generator().manual_seed(5)
@@ -95,7 +108,7 @@ def test_conv_exact_integer_layout(K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_conv_scatter_accumulate(K, dtype):
+def test_conv_scatter_accumulate(K, dtype, conv_bm):
     """strided scatter + read-modify-write epilogue (used by stride-2 data gradients)."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 64, 8, 8, generator=g)
@@ -387,7 +400,7 @@ def test_augment_bit_exact(K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_conv_relu_mask_epilogue(K, dtype):
+def test_conv_relu_mask_epilogue(K, dtype, conv_bm):
     """y = conv(x, w) * (mask > 0), alone and combined with accumulate + strided scatter."""
     g = torch.Generator().manual_seed(21)
     x = torch.randn(2, 64, 9, 9, generator=g)
@@ -408,6 +421,48 @@ def test_conv_relu_mask_epilogue(K, dtype):
     ref2 = base.clone().double()
     ref2[:, :, 0::2, 0::2] = (ref2[:, :, 0::2, 0::2] + F.conv2d(x.double(), wt.double(), None, 1, 1)) * (mask2[:, :, 0::2, 0::2] > 0)
     np.testing.assert_allclose(from_nhwc(out).numpy(), ref2.float().numpy(), **tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("variant", ["mask_tensor", "mask_from_y", "no_mask"])
+@pytest.mark.parametrize("case", [(2, 64, 9, 9, 128, 3, False), (3, 256, 7, 5, 64, 1, True), (2, 128, 8, 8, 64, 3, True), (1, 64, 40, 40, 192, 3, False)])
+def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm):
+    """MAAI_EPI_DGRAD_REDUCE: the stored gradient g equals the plain (accumulate + mask) epilogue's bit for bit,
+    and the partial sums equal those of the separate reduction pass over the stored g (sum g, sum g*(y - mean))."""
+    n, cin, h, w, cout, k, acc = case
+    g = torch.Generator().manual_seed(31 + cin + k)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ylow = torch.randn(n, cout, h, w, generator=g)
+    base = torch.randn(n, cout, h, w, generator=g)
+    mean, scale, shift = torch.randn(cout, generator=g), torch.randn(cout, generator=g), torch.randn(cout, generator=g) * 0.3
+    xd, wd, yd, bd = nhwc(x, dtype), khwc(wt, dtype), nhwc(ylow, dtype), nhwc(base, dtype)
+    mean_d, scale_d, shift_d = mean.cuda(), scale.cuda(), shift.cuda()
+    p = k // 2
+    if variant == "mask_tensor":
+        mask = nhwc(torch.randn(n, cout, h, w, generator=g), dtype)
+        sc = sh = None
+    elif variant == "mask_from_y":
+        mask = K.bn_act_fwd(yd, scale_d, shift_d, None, True)      # the ReLU output the mask stands for
+        sc, sh = scale_d, shift_d
+    else:
+        mask = sc = sh = None
+    want = bd.clone() if acc else torch.empty_like(bd)
+    K.conv2d(xd, wd, 1, p, p, out=want, grid_hw=(h, w), out_hw=(h, w), accumulate=acc, relu_mask=mask)
+    got = bd.clone() if acc else torch.empty_like(bd)
+    rows = K.conv2d_stats_rows(xd, wd, 1, p, p, (h, w), (h, w))
+    part = torch.full((rows, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    K.conv2d_store_reduce(xd, wd, 1, p, p, got, part, yd, mean_d, sc, sh, None if variant == "mask_from_y" else mask,
+                          grid_hw=(h, w), out_hw=(h, w), accumulate=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    sums = K.reduce_partials(part).cpu()
+    wf, yf = want.double().reshape(-1, cout), yd.double().reshape(-1, cout)
+    ref = torch.cat([wf.sum(0), (wf * (yf - mean_d.double())).sum(0)]).cpu()
+    np.testing.assert_allclose(sums.numpy(), ref.numpy(), rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 2e-2)
+    if (cout // (8 if dtype == torch.bfloat16 else 4)) in (8, 16, 32, 64, 128, 256):
+        sep = K.bn_act_bwd_reduce(want, None, yd, mean_d, False).cpu()
+        np.testing.assert_allclose(sums.numpy(), sep.numpy(), rtol=2e-5, atol=2e-4)
 
 
 @pytest.fixture(params=["0", "1"], ids=["lds-epilogue", "direct-epilogue"])

@@ -237,7 +237,7 @@ def test_every_block_teacher_forced(mods, arch, cm, shape, prec, fuse):
         # engine convention: the incoming gradient already carries the block output's ReLU mask and the
         # returned one carries the block input's (both folded into conv epilogues on the real path)
         dmask = engine.relu_mask_grad(dout.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), r3.out)
-        dx = engine.block_bwd(entry, dmask, grads, dtype)
+        dx, _ = engine.block_bwd(entry, dmask, grads, dtype)
         torch.cuda.synchronize()
 
         def direction(got_t, ref_t, name):
