@@ -96,6 +96,7 @@ typedef struct {
   const float* p2;   /* BWD_APPLY: k3; DGRAD_REDUCE: shift of the mask (nullable) */
   const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y;
                         DGRAD_REDUCE: the lower layer's raw conv output, laid out like y */
+  int mask_bits;     /* DGRAD_REDUCE, bf16: relu_mask is the 1-bit mask of maai_bn_act_fwd_mask, not a tensor */
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);
@@ -131,6 +132,12 @@ int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
  * multilayerPerceptron.py:13-14 with scale == NULL. */
 int maai_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                     long long M, int C, int relu, int dtype, void* stream);
+/* same, and (bf16 only, mask_bits nullable) the 1-bit-per-element ReLU mask of the stored output: byte i covers
+ * elements 8i..8i+7 of the NHWC tensor, bit e set where out > 0.  The backward pass of a residual block reads
+ * this (M*C/8 bytes) instead of the block output itself to mask the gradient (resnet.py:133 relu backward);
+ * consumed by maai_conv2d_igemm_fused with epi->mask_bits = 1. */
+int maai_bn_act_fwd_mask(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                         unsigned char* mask_bits, long long M, int C, int relu, int dtype, void* stream);
 /* backward pass 1: dz = dout * (out > 0 if relu); partial[rows][2][C] = per-block
  * column sums of dz and dz * (y - mean[c]).  rows = maai_bn_bwd_rows(M, C, dtype).
  * y/mean nullable (second sum left 0), out nullable when relu == 0.  Also the

@@ -9,10 +9,56 @@
 #include "maai_internal.h"
 
 // ---------------------------------------------------------------------------
-// partial[rows][C2] fp32 -> sums[C2] fp64 (atomic fp64 adds of per-block sums)
+// partial[rows][C2] fp32 -> sums[C2] fp64 (atomic fp64 adds of per-block sums).
+// The slabs are large at the full-resolution stages (one row per 128/256-pixel conv tile: 100k rows x 2C floats),
+// so this is a streaming pass like the others: 16 bytes per lane, L lanes per row (L = the largest power of two
+// <= 64 dividing C2/4), 256/L rows per pass, ~1k workgroups, four independent fp64 accumulators per lane.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, long long rows, int C2,
-                                                              double* __restrict__ sums, long long rows_per_block) {
+                                                              double* __restrict__ sums, long long rows_per_block, int L) {
+  __shared__ double red[256][4];
+  const int lr = threadIdx.x % L, slot = threadIdx.x / L, nslot = 256 / L;
+  const int col = (blockIdx.x * L + lr) * 4;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const float* p = partial + col;
+  long long r = r0 + slot;
+  for (; r + 3 * nslot < r1; r += 4 * nslot) {  // four rows in flight
+    const float4 a = *reinterpret_cast<const float4*>(p + r * C2);
+    const float4 b = *reinterpret_cast<const float4*>(p + (r + nslot) * C2);
+    const float4 c = *reinterpret_cast<const float4*>(p + (r + 2 * nslot) * C2);
+    const float4 d = *reinterpret_cast<const float4*>(p + (r + 3 * nslot) * C2);
+    s0 += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
+    s1 += ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+    s2 += ((double)a.z + (double)b.z) + ((double)c.z + (double)d.z);
+    s3 += ((double)a.w + (double)b.w) + ((double)c.w + (double)d.w);
+  }
+  for (; r < r1; r += nslot) {
+    const float4 a = *reinterpret_cast<const float4*>(p + r * C2);
+    s0 += (double)a.x;
+    s1 += (double)a.y;
+    s2 += (double)a.z;
+    s3 += (double)a.w;
+  }
+  red[threadIdx.x][0] = s0;
+  red[threadIdx.x][1] = s1;
+  red[threadIdx.x][2] = s2;
+  red[threadIdx.x][3] = s3;
+  __syncthreads();
+  // thread t < 4L: column (t/4 of this block's L groups, component t%4), summed over the row slots
+  if (threadIdx.x < 4 * L) {
+    const int g = threadIdx.x >> 2, e = threadIdx.x & 3;
+    double t = 0.0;
+    for (int k = 0; k < nslot; ++k) t += red[k * L + g][e];
+    atomicAdd(&sums[(blockIdx.x * L + g) * 4 + e], t);
+  }
+}
+
+// scalar fallback for column counts that are not a multiple of 4
+__global__ __launch_bounds__(256) void reduce_partials_scalar_kernel(const float* __restrict__ partial, long long rows, int C2,
+                                                                     double* __restrict__ sums, long long rows_per_block) {
   __shared__ double red[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
@@ -37,11 +83,25 @@ extern "C" int maai_reduce_partials(const float* partial, long long rows, int C2
     maai_set_error("reduce_partials: memset failed");
     return MAAI_ERR_LAUNCH;
   }
-  long long slices = (rows + 255) / 256;
-  if (slices > 64) slices = 64;
-  const long long rpb = (rows + slices - 1) / slices;
-  dim3 grid((C2 + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
-  hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, st, partial, rows, C2, sums, rpb);
+  if (C2 % 4 == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
+    const int c4 = C2 / 4;
+    int L = c4 & -c4;  // largest power of two dividing c4
+    if (L > 64) L = 64;
+    const int gx = c4 / L, nslot = 256 / L;
+    long long slices = (rows + 8LL * nslot - 1) / (8LL * nslot);  // >= 8 rows per row slot
+    const long long cap = 1024 / gx > 0 ? 1024 / gx : 1;
+    if (slices > cap) slices = cap;
+    if (slices < 1) slices = 1;
+    const long long rpb = (rows + slices - 1) / slices;
+    dim3 grid(gx, (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, st, partial, rows, C2, sums, rpb, L);
+  } else {
+    long long slices = (rows + 255) / 256;
+    if (slices > 64) slices = 64;
+    const long long rpb = (rows + slices - 1) / slices;
+    dim3 grid((C2 + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(reduce_partials_scalar_kernel, grid, dim3(256), 0, st, partial, rows, C2, sums, rpb);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -107,7 +167,8 @@ extern "C" int maai_bn_eval_coeffs(const float* gamma, const float* beta, const 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res,
-                                                         T* __restrict__ out, long long nchunks, int cpr, int relu) {
+                                                         T* __restrict__ out, unsigned char* __restrict__ bits,
+                                                         long long nchunks, int cpr, int relu) {
   constexpr int E = Vec16<T>::N;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % cpr) * E;
@@ -137,6 +198,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     }
     v.set(f);
     v.store(out + i * E);
+    if (E == 8 && bits) {  // 1-bit ReLU mask of the STORED value: byte i = elements 8i..8i+7, bit e = (out > 0)
+      v.get(f);
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+      bits[i] = (unsigned char)b;
+    }
   }
 }
 
@@ -149,7 +217,13 @@ static inline unsigned stream_grid(long long nchunks) {
 
 extern "C" int maai_bn_act_fwd(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                                long long M, int C, int relu, int dtype, void* stream) {
+  return maai_bn_act_fwd_mask(y, scale, shift, residual, out, nullptr, M, C, relu, dtype, stream);
+}
+
+extern "C" int maai_bn_act_fwd_mask(const void* y, const float* scale, const float* shift, const void* residual, void* out,
+                                    unsigned char* mask_bits, long long M, int C, int relu, int dtype, void* stream) {
   MAAI_CHECK_ARG(y && out && M > 0 && C > 0, "bn_act_fwd: bad arguments");
+  MAAI_CHECK_ARG(!mask_bits || dtype == MAAI_BF16, "bn_act_fwd: the 1-bit mask is produced for bf16 tensors only");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_fwd: bad dtype");
   const int E = dtype == MAAI_BF16 ? 8 : 4;
   MAAI_CHECK_ARG(C % E == 0, "bn_act_fwd: C must be a multiple of 8 (bf16) / 4 (f32)");
@@ -157,10 +231,10 @@ extern "C" int maai_bn_act_fwd(const void* y, const float* scale, const float* s
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == MAAI_BF16)
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)y, scale,
-                       shift, (const bf16_t*)residual, (bf16_t*)out, nchunks, C / E, relu);
+                       shift, (const bf16_t*)residual, (bf16_t*)out, mask_bits, nchunks, C / E, relu);
   else
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)y, scale,
-                       shift, (const float*)residual, (float*)out, nchunks, C / E, relu);
+                       shift, (const float*)residual, (float*)out, nullptr, nchunks, C / E, relu);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

@@ -71,13 +71,14 @@ struct ConvArgs {
   const float* ep1;
   const float* ep2;
   const void* et;
+  int mask_bits;  // mask is a 1-bit-per-element array (maai_bn_act_fwd_mask), EMODE 6 / 16-bit types only
 };
 
 // EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
 // 6 = 5 plus the BN-backward partial sums of the stored gradient (MAAI_EPI_DGRAD_REDUCE).
 // PW: pointwise stride-1 layer (input pixel == output pixel): no row decode, no tap loop, no bounds tests.
 template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
-__global__ __launch_bounds__(256, BM == 256 ? 2 : 1) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
   constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
@@ -302,6 +303,93 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 1) void conv_igemm_kernel(Conv
   const bool full = dense && ((long long)(mb + 1) * BM <= a.M);
   const long long off0 = ((long long)mb * BM + ph * CROWS + tid / CPR) * a.Cout + nb * BN + chf * EPC;
   const long long ostep = (long long)RPI * a.Cout;
+  if constexpr (EMODE == 5 || EMODE == 6) {
+    // Read-modify-write epilogues.  The stores of one iteration may alias the loads of the next as far as the
+    // compiler can tell, which would serialise eight load -> store round trips per thread; so the global loads
+    // of NB iterations (previous content, the lower layer's y, the mask) are issued together, then consumed.
+    constexpr int NIT = (BM < CROWS ? BM : CROWS) / RPI;
+    constexpr int NB = (NIT % 4 == 0 && BM < 256) ? 4 : (NIT % 2 == 0 ? 2 : 1);  // (4 would spill under the 256-row tile)
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += NB) {
+      long long ooffs[NB];
+      bool ok[NB];
+      Vec16<T> vo[NB], vy[NB], vm[NB];
+      unsigned mb8[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int it = it0 + b;
+        const int row = tid / CPR + it * RPI;
+        long long ooff = off0 + it * ostep;
+        ok[b] = true;
+        if (!full) {
+          const long long m = (long long)mb * BM + ph * CROWS + row;
+          ok[b] = m < a.M;
+          long long opix = m;
+          if (!dense) {
+            const unsigned mu = (unsigned)m;
+            const unsigned n = mu / ohw;
+            const unsigned rem = mu - n * ohw;
+            const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
+            opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
+          }
+          ooff = opix * a.Cout + nb * BN + chf * EPC;
+        }
+        ooffs[b] = ooff;
+        mb8[b] = 0;
+        if (ok[b]) {
+          if (a.accumulate) vo[b].load(y + ooff);
+          if constexpr (EMODE == 6) vy[b].load(reinterpret_cast<const T*>(a.et) + ooff);
+          if (a.mask) {
+            if (EMODE == 6 && NV == 8 && a.mask_bits)
+              mb8[b] = reinterpret_cast<const unsigned char*>(a.mask)[ooff >> 3];
+            else
+              vm[b].load(reinterpret_cast<const T*>(a.mask) + ooff);
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!ok[b]) continue;
+        const int row = tid / CPR + (it0 + b) * RPI;
+        Vec16<T> v;
+        v.load(ct + row * LDC + chf * EPC);
+        float fv[NV];
+        v.get(fv);
+        if (a.accumulate) {
+          float fo[NV];
+          vo[b].get(fo);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) fv[e] += fo[e];
+        }
+        float fy[NV];
+        if constexpr (EMODE == 6) vy[b].get(fy);
+        if (a.mask) {
+          if (EMODE == 6 && NV == 8 && a.mask_bits) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) fv[e] = ((mb8[b] >> e) & 1u) ? fv[e] : 0.f;
+          } else {
+            float fm[NV];
+            vm[b].get(fm);
+#pragma unroll
+            for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
+          }
+        } else if (EMODE == 6 && a.ep1 && a.ep2) {  // the lower layer's ReLU output is positive exactly where y*scale + shift is
+#pragma unroll
+          for (int e = 0; e < NV; ++e) fv[e] = (fy[e] * q1[e] + q2[e]) > 0.f ? fv[e] : 0.f;
+        }
+        v.set(fv);
+        if constexpr (EMODE == 6) {
+          v.get(fv);  // the rounded value being stored is what a separate reduction pass would read back
+#pragma unroll
+          for (int e = 0; e < NV; ++e) {
+            s1[e] += fv[e];
+            s2[e] += fv[e] * (fy[e] - q0[e]);
+          }
+        }
+        v.store(y + ooffs[b]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int it = 0; it < (BM < CROWS ? BM : CROWS) / RPI; ++it) {
     const int row = tid / CPR + it * RPI, ch = chf;
@@ -364,61 +452,8 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 1) void conv_igemm_kernel(Conv
       }
       continue;
     }
-    if constexpr (EMODE == 6) {
-      float fv[NV], fy[NV];
-      v.get(fv);
-      if (a.accumulate) {
-        Vec16<T> o;
-        o.load(dst);
-        float fo[NV];
-        o.get(fo);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] += fo[e];
-      }
-      Vec16<T> yv;
-      yv.load(reinterpret_cast<const T*>(a.et) + ooff);
-      yv.get(fy);
-      if (a.mask) {
-        Vec16<T> mk;
-        mk.load(reinterpret_cast<const T*>(a.mask) + ooff);
-        float fm[NV];
-        mk.get(fm);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
-      } else if (a.ep1 && a.ep2) {  // the lower layer's ReLU output is positive exactly where y*scale + shift is
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] = (fy[e] * q1[e] + q2[e]) > 0.f ? fv[e] : 0.f;
-      }
-      v.set(fv);
-      v.get(fv);  // the rounded value being stored is what a separate reduction pass would read back
-#pragma unroll
-      for (int e = 0; e < NV; ++e) {
-        s1[e] += fv[e];
-        s2[e] += fv[e] * (fy[e] - q0[e]);
-      }
-    }
-    if constexpr (EMODE == 5) {
-      float fv[NV];
-      v.get(fv);
-      if (a.accumulate) {
-        Vec16<T> o;
-        o.load(dst);
-        float fo[NV];
-        o.get(fo);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] += fo[e];
-      }
-      if (a.mask) {
-        Vec16<T> mk;
-        mk.load(reinterpret_cast<const T*>(a.mask) + ooff);
-        float fm[NV];
-        mk.get(fm);
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
-      }
-      v.set(fv);
-    }
     v.store(dst);
+  }
   }
   }  // phases
   if constexpr (EMODE == 3 || EMODE == 6) {
@@ -571,6 +606,9 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.ep1 = epi ? epi->p1 : nullptr;
   a.ep2 = epi ? epi->p2 : nullptr;
   a.et = epi ? epi->t : nullptr;
+  a.mask_bits = epi ? epi->mask_bits : 0;
+  MAAI_CHECK_ARG(!a.mask_bits || (emode == MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && relu_mask),
+                 "conv2d_igemm: the 1-bit mask is for the bf16 DGRAD_REDUCE epilogue");
   a.M = (long long)d->N * d->OHg * d->OWg;
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -154,7 +154,7 @@ def w_linear_dgrad(param, dtype, nhwc_from=None):
 # ----------------------------------------------------------------------------
 class _Rec(object):
     __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
-                 "count", "world", "training", "form", "in_hw", "fused", "shift")
+                 "count", "world", "training", "form", "in_hw", "fused", "shift", "bits")
 
 
 # Pointwise expanding convolutions with few input channels (conv3 / downsample of the first stages) are HBM-bound
@@ -235,9 +235,15 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused, r.shift = (x.shape[1], x.shape[2]), True, shift
+        r.in_hw, r.fused, r.shift, r.bits = (x.shape[1], x.shape[2]), True, shift, None
         return out, r
-    out = K.bn_act_fwd(y, scale, shift, residual, relu)
+    # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
+    # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
+    bits = None
+    if keep and relu and residual is not None and y.dtype == torch.bfloat16 and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"]:
+        out, bits = K.bn_act_fwd(y, scale, shift, residual, relu, want_bits=True)
+    else:
+        out = K.bn_act_fwd(y, scale, shift, residual, relu)
     if not keep:
         return out, None
     r = _Rec()
@@ -245,14 +251,15 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
-    r.fused, r.shift = False, shift
+    r.fused, r.shift, r.bits = False, shift, bits
     return out, r
 
 
 # The BatchNorm-backward reduction of a unit (sums of dz and dz*(y - mean)) rides the epilogue of the data-gradient
 # convolution that PRODUCES dz, instead of a separate pass that reads dz and y back (MAAI_EPI_DGRAD_REDUCE); the
 # ReLU mask of a plain conv-bn-relu unit then comes from y*scale + shift > 0, so its output is not read either.
-_DGRAD_REDUCE = {"enabled": os.environ.get("MAAI_DGRAD_REDUCE", "1") != "0"}
+_DGRAD_REDUCE = {"enabled": os.environ.get("MAAI_DGRAD_REDUCE", "1") != "0",
+                 "bits": os.environ.get("MAAI_MASK_BITS", "1") != "0"}
 
 
 def _reduce_mean(rec):
@@ -280,6 +287,9 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
             raise MaaiError("conv_dgrad: the unit below has no ReLU to take a mask from")
         from_y = fuse and not below.has_res
         relu_mask = None if from_y else below.out
+    use_bits = fuse and below.has_res and getattr(below, "bits", None) is not None
+    if use_bits:
+        relu_mask = below.bits
     launches = []
     for (a, khs, pad_h) in cls:
         for (b, kws, pad_w) in cls:
@@ -300,7 +310,8 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
     for (wq, pad_h, pad_w, grid, off), nr in zip(launches, rows):
         K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], below.y, _reduce_mean(below),
                               below.scale if from_y else None, below.shift if from_y else None, relu_mask,
-                              grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate)
+                              grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate,
+                              mask_bits=use_bits)
         r0 += nr
     return out, K.reduce_partials(slab)
 

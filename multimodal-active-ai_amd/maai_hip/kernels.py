@@ -142,26 +142,30 @@ def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=Non
 
 
 def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
-                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False):
+                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False):
     """conv2d(..., out=out) for a data gradient whose epilogue also reduces the BatchNorm-backward partial sums of
     the stored values g: rows of ``part`` [rows,2,Cout] get sum(g) and sum(g*(lower_y - mean)).  The ReLU mask is
     ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE)."""
     _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask)
     if x.dtype != w.dtype or lower_y.dtype != out.dtype or lower_y.shape != out.shape:
         raise MaaiError("conv2d_store_reduce: operand dtype / shape mismatch")
-    if relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
+    if mask_bits:
+        if relu_mask is None or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 8 != out.numel() or out.dtype != torch.bfloat16:
+            raise MaaiError("conv2d_store_reduce: the 1-bit mask must be uint8 [numel/8] over a bf16 output")
+    elif relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
         raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
     rows = int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
     if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != (rows, 2, d.Cout):
         raise MaaiError("conv2d_store_reduce: partial slab must be fp32 [%d, 2, %d]" % (rows, d.Cout))
     epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
-                       None if shift is None else shift.data_ptr(), lower_y.data_ptr())
+                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0)
     m = d.N * d.OHg * d.OWg
     es = x.element_size()
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[red] M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
-                es * (x.numel() + w.numel() + m * d.Cout * (2 + (1 if accumulate else 0) + (1 if relu_mask is not None else 0)))):
+                es * (x.numel() + w.numel() + m * d.Cout * (2 + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
+                + (m * d.Cout // 8 if mask_bits else 0)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")
     return out
@@ -298,16 +302,19 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return scale, shift
 
 
-def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None):
+def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None, want_bits=False):
+    """out = act(y*scale + shift (+ residual)); with ``want_bits`` (bf16) also the 1-bit ReLU mask of out
+    (uint8 [numel/8]) -> (out, bits)."""
     _gpu(y, scale, shift, residual, out)
     c = y.shape[-1]
     m = y.numel() // c
     if out is None:
         out = torch.empty_like(y)
-    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * (3 if residual is not None else 2)):
-        check(lib().maai_bn_act_fwd(_p(y), _p(scale), _p(shift), _p(residual), _p(out), m, c, 1 if relu else 0, _dt(y), _stream()),
-              "maai_bn_act_fwd")
-    return out
+    bits = torch.empty((y.numel() // 8,), dtype=torch.uint8, device=y.device) if want_bits else None
+    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * (3 if residual is not None else 2) + (y.numel() // 8 if want_bits else 0)):
+        check(lib().maai_bn_act_fwd_mask(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits), m, c, 1 if relu else 0,
+                                         _dt(y), _stream()), "maai_bn_act_fwd_mask")
+    return (out, bits) if want_bits else out
 
 
 def bn_act_bwd_reduce(dout, out, y, mean, relu):

@@ -424,7 +424,7 @@ def test_conv_relu_mask_epilogue(K, dtype, conv_bm):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("variant", ["mask_tensor", "mask_from_y", "no_mask"])
+@pytest.mark.parametrize("variant", ["mask_tensor", "mask_from_y", "mask_bits", "no_mask"])
 @pytest.mark.parametrize("case", [(2, 64, 9, 9, 128, 3, False), (3, 256, 7, 5, 64, 1, True), (2, 128, 8, 8, 64, 3, True), (1, 64, 40, 40, 192, 3, False)])
 def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm):
     """MAAI_EPI_DGRAD_REDUCE: the stored gradient g equals the plain (accumulate + mask) epilogue's bit for bit,
@@ -439,7 +439,17 @@ def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm):
     xd, wd, yd, bd = nhwc(x, dtype), khwc(wt, dtype), nhwc(ylow, dtype), nhwc(base, dtype)
     mean_d, scale_d, shift_d = mean.cuda(), scale.cuda(), shift.cuda()
     p = k // 2
-    if variant == "mask_tensor":
+    bits = None
+    if variant == "mask_bits":
+        if dtype != torch.bfloat16:
+            pytest.skip("the 1-bit mask exists for bf16 only")
+        res = nhwc(torch.randn(n, cout, h, w, generator=g), dtype)
+        mask, bits = K.bn_act_fwd(yd, scale_d, shift_d, res, True, want_bits=True)   # a residual unit's output + its bits
+        assert torch.equal(mask, K.bn_act_fwd(yd, scale_d, shift_d, res, True))
+        packed = np.packbits((mask.float().cpu().numpy().reshape(-1) > 0).astype(np.uint8), bitorder="little")
+        assert np.array_equal(bits.cpu().numpy(), packed)
+        sc = sh = None
+    elif variant == "mask_tensor":
         mask = nhwc(torch.randn(n, cout, h, w, generator=g), dtype)
         sc = sh = None
     elif variant == "mask_from_y":
@@ -452,8 +462,9 @@ def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm):
     got = bd.clone() if acc else torch.empty_like(bd)
     rows = K.conv2d_stats_rows(xd, wd, 1, p, p, (h, w), (h, w))
     part = torch.full((rows, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
-    K.conv2d_store_reduce(xd, wd, 1, p, p, got, part, yd, mean_d, sc, sh, None if variant == "mask_from_y" else mask,
-                          grid_hw=(h, w), out_hw=(h, w), accumulate=acc)
+    K.conv2d_store_reduce(xd, wd, 1, p, p, got, part, yd, mean_d, sc, sh,
+                          None if variant == "mask_from_y" else (bits if bits is not None else mask),
+                          grid_hw=(h, w), out_hw=(h, w), accumulate=acc, mask_bits=bits is not None)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     sums = K.reduce_partials(part).cpu()
