@@ -138,6 +138,17 @@ int maai_bn_act_fwd(const void* y, const float* scale, const float* shift, const
  * consumed by maai_conv2d_igemm_fused with epi->mask_bits = 1. */
 int maai_bn_act_fwd_mask(const void* y, const float* scale, const float* shift, const void* residual, void* out,
                          unsigned char* mask_bits, long long M, int C, int relu, int dtype, void* stream);
+/* Two normalised branches in one pass (first block of a stage, resnet.py:126-133 with a downsample):
+ * out = act((y*scale + shift) + r(y2*scale2 + shift2)), r = rounding to the storage type, so the result is
+ * bit-identical to maai_bn_act_fwd(y2 -> idn) followed by maai_bn_act_fwd(y, residual = idn) without ever
+ * storing idn.  mask_bits as above (nullable).  The backward counterpart reads the shared gradient once:
+ * dy = k1*dz - k2 - k3*y and dy2 = k1b*dz - k2b - k3b*y2. */
+int maai_bn_act_fwd2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
+                     const float* shift2, void* out, unsigned char* mask_bits, long long M, int C, int relu, int dtype,
+                     void* stream);
+int maai_bn_act_bwd_apply2(const void* dz, const void* y, const float* k1, const float* k2, const float* k3,
+                           const void* y2, const float* k1b, const float* k2b, const float* k3b, void* dy, void* dy2,
+                           long long M, int C, int dtype, void* stream);
 /* backward pass 1: dz = dout * (out > 0 if relu); partial[rows][2][C] = per-block
  * column sums of dz and dz * (y - mean[c]).  rows = maai_bn_bwd_rows(M, C, dtype).
  * y/mean nullable (second sum left 0), out nullable when relu == 0.  Also the

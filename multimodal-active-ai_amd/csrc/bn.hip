@@ -208,6 +208,47 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
+// The first block of a stage adds two normalised branches (resnet.py:126-133 with a downsample: out =
+// relu(bn3(y3) + bn_d(y_d))).  Doing it in one pass — out = act((y*s + t) + r(y2*s2 + t2)) — saves writing the
+// normalised shortcut and reading it back (8 of 20 tensor passes).  r() rounds the shortcut to the storage type
+// first, so the result is bit-identical to the two-pass sequence it replaces.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd2_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const T* __restrict__ y2,
+                                                          const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                          T* __restrict__ out, unsigned char* __restrict__ bits,
+                                                          long long nchunks, int cpr, int relu) {
+  constexpr int E = Vec16<T>::N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * E;
+    Vec16<T> v, w;
+    v.load(y + i * E);
+    w.load(y2 + i * E);
+    float f[E], g[E];
+    v.get(f);
+    w.get(g);
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = g[e] * scale2[c + e] + shift2[c + e];
+    w.set(g);
+    w.get(g);  // the shortcut as the two-pass path would have stored it
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] = (f[e] * scale[c + e] + shift[c + e]) + g[e];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    v.set(f);
+    v.store(out + i * E);
+    if (E == 8 && bits) {
+      v.get(f);
+      unsigned b = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
+      bits[i] = (unsigned char)b;
+    }
+  }
+}
+
 static inline unsigned stream_grid(long long nchunks) {
   long long g = (nchunks + 255) / 256;
   if (g > 8192) g = 8192;
@@ -437,6 +478,77 @@ extern "C" int maai_bn_act_bwd_apply(const void* dout, const void* out, const vo
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)dout,
                        (const float*)out, (const float*)y, k1, k2, k3, (float*)dy, (float*)dz_out, nchunks, C / E, relu);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+extern "C" int maai_bn_act_fwd2(const void* y, const float* scale, const float* shift, const void* y2, const float* scale2,
+                                const float* shift2, void* out, unsigned char* mask_bits, long long M, int C, int relu,
+                                int dtype, void* stream) {
+  MAAI_CHECK_ARG(y && y2 && scale && shift && scale2 && shift2 && out && M > 0 && C > 0, "bn_act_fwd2: bad arguments");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_fwd2: bad dtype");
+  MAAI_CHECK_ARG(!mask_bits || dtype == MAAI_BF16, "bn_act_fwd2: the 1-bit mask is produced for bf16 tensors only");
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  MAAI_CHECK_ARG(C % E == 0, "bn_act_fwd2: C must be a multiple of 8 (bf16) / 4 (f32)");
+  const long long nchunks = M * (C / E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16)
+    hipLaunchKernelGGL(bn_act_fwd2_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)y, scale,
+                       shift, (const bf16_t*)y2, scale2, shift2, (bf16_t*)out, mask_bits, nchunks, C / E, relu);
+  else
+    hipLaunchKernelGGL(bn_act_fwd2_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)y, scale,
+                       shift, (const float*)y2, scale2, shift2, (float*)out, nullptr, nchunks, C / E, relu);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+// backward of the same pair: both branches receive the same gradient dz, read once
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const T* __restrict__ dz, const T* __restrict__ y,
+                                                            const float* __restrict__ k1, const float* __restrict__ k2,
+                                                            const float* __restrict__ k3, const T* __restrict__ y2,
+                                                            const float* __restrict__ k1b, const float* __restrict__ k2b,
+                                                            const float* __restrict__ k3b, T* __restrict__ dy,
+                                                            T* __restrict__ dy2, long long nchunks, int cpr) {
+  constexpr int E = Vec16<T>::N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nchunks; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * E;
+    Vec16<T> vd, va, vb;
+    vd.load(dz + i * E);
+    va.load(y + i * E);
+    vb.load(y2 + i * E);
+    float d[E], a[E], b[E];
+    vd.get(d);
+    va.get(a);
+    vb.get(b);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = k1[c + e] * d[e] - k2[c + e] - k3[c + e] * a[e];
+      b[e] = k1b[c + e] * d[e] - k2b[c + e] - k3b[c + e] * b[e];
+    }
+    va.set(a);
+    vb.set(b);
+    va.store(dy + i * E);
+    vb.store(dy2 + i * E);
+  }
+}
+
+extern "C" int maai_bn_act_bwd_apply2(const void* dz, const void* y, const float* k1, const float* k2, const float* k3,
+                                      const void* y2, const float* k1b, const float* k2b, const float* k3b, void* dy,
+                                      void* dy2, long long M, int C, int dtype, void* stream) {
+  MAAI_CHECK_ARG(dz && y && y2 && k1 && k2 && k3 && k1b && k2b && k3b && dy && dy2 && M > 0 && C > 0,
+                 "bn_act_bwd_apply2: bad arguments");
+  MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "bn_act_bwd_apply2: bad dtype");
+  const int E = dtype == MAAI_BF16 ? 8 : 4;
+  MAAI_CHECK_ARG(C % E == 0, "bn_act_bwd_apply2: C must be a multiple of 8 (bf16) / 4 (f32)");
+  const long long nchunks = M * (C / E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16)
+    hipLaunchKernelGGL(bn_bwd_apply2_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)dz,
+                       (const bf16_t*)y, k1, k2, k3, (const bf16_t*)y2, k1b, k2b, k3b, (bf16_t*)dy, (bf16_t*)dy2, nchunks, C / E);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply2_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)dz,
+                       (const float*)y, k1, k2, k3, (const float*)y2, k1b, k2b, k3b, (float*)dy, (float*)dy2, nchunks, C / E);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

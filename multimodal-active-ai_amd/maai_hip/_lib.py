@@ -48,6 +48,8 @@ SIGNATURES = {
     "maai_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "maai_bn_act_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_bn_act_fwd_mask": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "maai_bn_act_fwd2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
+    "maai_bn_act_bwd_apply2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p]),
     "maai_bn_bwd_rows": (c_ll, [c_ll, c_i, c_i]),
     "maai_bn_act_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_bn_bwd_coeffs": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),

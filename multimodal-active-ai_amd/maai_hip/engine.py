@@ -185,8 +185,14 @@ def _check_conv(conv):
         raise MaaiError("HIP path expects bias-free convolutions (resnet.py:22,28)")
 
 
-def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
-    """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None)."""
+_DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
+
+
+def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None):
+    """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).
+    ``defer``: stop after the statistics — returns ((y, scale, shift), rec) with rec.out = None, for a shortcut
+    branch whose normalisation is applied by the unit it is added to; ``branch`` = such a (y2, scale2, shift2)
+    triple, applied and added in this unit's single BN pass (maai_bn_act_fwd2) in place of ``residual``."""
     _check_conv(conv)
     k = conv.kernel_size[0]
     stride, pad = conv.stride[0], conv.padding[0]
@@ -195,7 +201,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     training = bn.training or (bn.running_mean is None)
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
-    fused = _fusable(conv, form)
+    fused = _fusable(conv, form) and not defer and branch is None
     y = None
     if training:
         if fused:
@@ -240,19 +246,31 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd"):
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
     bits = None
-    if keep and relu and residual is not None and y.dtype == torch.bfloat16 and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"]:
+    want_bits = (keep and relu and (residual is not None or branch is not None) and y.dtype == torch.bfloat16
+                 and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"])
+    if defer:
+        if relu or residual is not None or branch is not None:
+            raise MaaiError("unit_fwd: a deferred unit is a plain conv + BN shortcut branch")
+        out = None
+    elif branch is not None:
+        if residual is not None:
+            raise MaaiError("unit_fwd: residual and branch are exclusive")
+        out = K.bn_act_fwd2(y, scale, shift, branch[0], branch[1], branch[2], relu, want_bits=want_bits)
+        if want_bits:
+            out, bits = out
+    elif want_bits:
         out, bits = K.bn_act_fwd(y, scale, shift, residual, relu, want_bits=True)
     else:
         out = K.bn_act_fwd(y, scale, shift, residual, relu)
     if not keep:
-        return out, None
+        return ((y, scale, shift) if defer else out), None
     r = _Rec()
     r.x, r.y, r.out, r.conv, r.bn = x, y, out, conv, bn
-    r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
+    r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
     r.fused, r.shift, r.bits = False, shift, bits
-    return out, r
+    return ((y, scale, shift) if defer else out), r
 
 
 # The BatchNorm-backward reduction of a unit (sums of dz and dz*(y - mean)) rides the epilogue of the data-gradient
@@ -328,22 +346,17 @@ def _grad_to_reference(rec, dw):
     return g.contiguous()
 
 
-def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None, below=None,
-             presums=None):
-    """Backward of unit_fwd.  CONVENTION: ``dout`` is already multiplied by the ReLU mask of this unit's
-    output (the kernel that produced it folded ``* (out > 0)`` into its epilogue), so nothing here reads the
-    forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way;
-    ``below`` = the record of the unit that produced that input (mask AND, where possible, its BN-backward sums
-    from the same epilogue).  ``presums`` = this unit's own sums if the producer of ``dout`` already reduced them.
-    Returns (dx or None, sums for ``below`` or None); parameter gradients go to ``grads``."""
+def unit_bwd_coeffs(rec, dout, grads, dtype, presums=None):
+    """BatchNorm-backward coefficients (k1, k2, k3) of a unit — dy = k1*dz - k2 - k3*y — from the sums of dz and
+    dz*(y - mean) (``presums`` if the producer of dz reduced them, else one reduction pass); stores the BatchNorm
+    parameter gradients in ``grads``."""
     bn = rec.bn
-    wq_f = w_fwd(rec.conv.weight, dtype) if rec.fused else None
 
     def reduce(mean):
         if presums is not None:
             return presums
         if rec.fused:   # raw conv output never stored: recompute it inside the reduction
-            return K.conv2d_bwd_reduce(rec.x, wq_f, dout, mean)
+            return K.conv2d_bwd_reduce(rec.x, w_fwd(rec.conv.weight, dtype), dout, mean)
         return K.bn_act_bwd_reduce(dout, None, rec.y, mean, False)
     if rec.training:
         sums = reduce(rec.mean)
@@ -366,10 +379,24 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         grads[id(bn.weight)] = dgamma
     if bn.bias is not None and bn.bias.requires_grad:
         grads[id(bn.bias)] = dbeta
-    if rec.fused:
-        dy = K.conv2d_bwd_apply(rec.x, wq_f, dout, k1, k2, k3)
-    else:
-        dy, _ = K.bn_act_bwd_apply(dout, None, rec.y, k1, k2, k3, False, True, False)
+    return k1, k2, k3
+
+
+def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None, below=None,
+             presums=None, dy=None):
+    """Backward of unit_fwd.  CONVENTION: ``dout`` is already multiplied by the ReLU mask of this unit's
+    output (the kernel that produced it folded ``* (out > 0)`` into its epilogue), so nothing here reads the
+    forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way;
+    ``below`` = the record of the unit that produced that input (mask AND, where possible, its BN-backward sums
+    from the same epilogue).  ``presums`` = this unit's own sums if the producer of ``dout`` already reduced them;
+    ``dy`` = the gradient wrt the raw conv output if the caller already ran the BatchNorm backward.
+    Returns (dx or None, sums for ``below`` or None); parameter gradients go to ``grads``."""
+    if dy is None:
+        k1, k2, k3 = unit_bwd_coeffs(rec, dout, grads, dtype, presums)
+        if rec.fused:
+            dy = K.conv2d_bwd_apply(rec.x, w_fwd(rec.conv.weight, dtype), dout, k1, k2, k3)
+        else:
+            dy, _ = K.bn_act_bwd_apply(dout, None, rec.y, k1, k2, k3, False, True, False)
     w = rec.conv.weight
     if w.requires_grad:
         kh = 7 if rec.form == "stem_unrolled" else rec.k
@@ -447,11 +474,16 @@ def backbone_fwd(resnet, x, dtype, keep):
             r2 = None
             last_conv, last_bn = blk.conv2, blk.bn2
         rd = None
-        if blk.downsample is not None:
-            idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep)
+        if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
+            # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored
+            br, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True)
+            out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br)
         else:
-            idn = xin
-        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep)
+            if blk.downsample is not None:
+                idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep)
+            else:
+                idn = xin
+            out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep)
         tape.append(("block", r1, r2, r3, rd))
     return out, tape
 
@@ -463,7 +495,16 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
     ``prev`` = record of the unit that produced the block input, ``presums`` = the last unit's BN-backward sums
     when the producer of ``dout`` reduced them.  Returns (dx, sums for ``prev`` or None)."""
     _, r1, r2, r3, rd = entry
-    d, s = unit_bwd(r3, dout, grads, dtype, below=r2 if r2 is not None else r1, presums=presums)
+    dyd = None
+    if rd is not None and _DUAL_BN["enabled"] and not r3.fused and not rd.fused:
+        # both branches receive the same gradient: one pass reads it once and writes both dy
+        k3 = unit_bwd_coeffs(r3, dout, grads, dtype, presums)
+        kd = unit_bwd_coeffs(rd, dout, grads, dtype)
+        dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
+        d, s = unit_bwd(r3, None, grads, dtype, below=r2 if r2 is not None else r1, dy=dy3)
+        del dy3
+    else:
+        d, s = unit_bwd(r3, dout, grads, dtype, below=r2 if r2 is not None else r1, presums=presums)
     if r2 is not None:
         d, s = unit_bwd(r2, d, grads, dtype, below=r1, presums=s)
     if rd is not None:
@@ -473,9 +514,9 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
         #  only if it rewrites every pixel (stride-1 downsample); otherwise ``prev`` reduces them itself.
         dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x, presums=s)
         if prev is not None:
-            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev)
+            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
         else:
-            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x)
+            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x, dy=dyd)
     else:
         # identity shortcut: dx = dout + dgrad(conv1), accumulated in place in the conv epilogue
         if prev is not None:

@@ -317,6 +317,33 @@ def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fa
     return (out, bits) if want_bits else out
 
 
+def bn_act_fwd2(y, scale, shift, y2, scale2, shift2, relu=True, want_bits=False):
+    """out = act((y*scale + shift) + round(y2*scale2 + shift2)) in one pass (two BatchNorm branches meeting)."""
+    _gpu(y, scale, shift, y2, scale2, shift2)
+    if y.shape != y2.shape or y.dtype != y2.dtype:
+        raise MaaiError("bn_act_fwd2: the two branches must share shape and dtype")
+    c = y.shape[-1]
+    m = y.numel() // c
+    out = torch.empty_like(y)
+    bits = torch.empty((y.numel() // 8,), dtype=torch.uint8, device=y.device) if want_bits else None
+    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * 3 + (y.numel() // 8 if want_bits else 0)):
+        check(lib().maai_bn_act_fwd2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), _p(bits), m, c,
+                                     1 if relu else 0, _dt(y), _stream()), "maai_bn_act_fwd2")
+    return (out, bits) if want_bits else out
+
+
+def bn_act_bwd_apply2(dz, y, k, y2, kb):
+    """(k1*dz - k2 - k3*y, k1b*dz - k2b - k3b*y2) with dz read once; k, kb = (k1, k2, k3) triples."""
+    _gpu(dz, y, y2, *k, *kb)
+    c = dz.shape[-1]
+    m = dz.numel() // c
+    dy, dy2 = torch.empty_like(dz), torch.empty_like(dz)
+    with _timed("bn_bwd_apply", 0.0, dz.element_size() * dz.numel() * 5):
+        check(lib().maai_bn_act_bwd_apply2(_p(dz), _p(y), _p(k[0]), _p(k[1]), _p(k[2]), _p(y2), _p(kb[0]), _p(kb[1]), _p(kb[2]),
+                                           _p(dy), _p(dy2), m, c, _dt(dz), _stream()), "maai_bn_act_bwd_apply2")
+    return dy, dy2
+
+
 def bn_act_bwd_reduce(dout, out, y, mean, relu):
     """fp64 sums [2C]: sum dz, sum dz*(y-mean)."""
     _gpu(dout, out, y, mean)
