@@ -72,19 +72,28 @@ struct ConvArgs {
   const float* ep2;
   const void* et;
   int mask_bits;  // mask is a 1-bit-per-element array (maai_bn_act_fwd_mask), EMODE 6 / 16-bit types only
+  int tilesX, tilesY;  // HALO kernels: 16-wide x BM/16-high output patches per image
 };
 
 // EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
 // 6 = 5 plus the BN-backward partial sums of the stored gradient (MAAI_EPI_DGRAD_REDUCE).
 // PW: pointwise stride-1 layer (input pixel == output pixel): no row decode, no tap loop, no bounds tests.
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
+// HALO: 3x3 stride-1 same-size layers.  The M tile is a 16-wide x BM/16-high patch of output pixels of ONE image
+// and the A operand is its (BM/16+2) x 18 input halo, staged once per 32-channel chunk and read by all nine taps
+// at shifted pixel addresses, instead of nine separately staged 64-byte row sets: 2.3-3.4x fewer LDS-DMA bytes per
+// MFMA on the layers whose K loop is bound by exactly that traffic.  K order: chunk-major, tap-minor.
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
   constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
   constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   constexpr int AR = BM / 64, BR = BN / 64;  // rows staged per thread
-  constexpr int STAGE = (BM + BN) * 64;      // bytes per buffer
+  constexpr int STAGE = HALO ? BN * 64 : (BM + BN) * 64;  // bytes per ring buffer (HALO: weights only)
+  constexpr int TH = BM / 16;                // HALO: patch height; halo image = (TH+2) rows x 24 pixel slots (18 used)
+  constexpr int HROWS = (TH + 2) * 24;       //       pixel slots of 64 bytes
+  constexpr int NH = (HROWS + 63) / 64;      //       LDS-DMA instructions per thread per halo
+  constexpr int HSLOT = NH * 4096;           //       bytes per halo buffer (two of them after the weight ring)
   constexpr int LDC = BN + EPC;              // C-tile row pitch (elements), 16-B padded
   typedef typename Mma<T>::frag frag_t;
 
@@ -94,6 +103,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
   const int wm = wid / WGN, wn = wid % WGN;
   const int logical = xcd_remap(blockIdx.x, a.nMB * a.nNB);
   const int mb = logical / a.nNB, nb = logical - mb * a.nNB;
+  // HALO: patch origin of this tile
+  int hn = 0, oy0 = 0, ox0 = 0;
+  if constexpr (HALO) {
+    const int tpi = a.tilesX * a.tilesY;
+    hn = mb / tpi;
+    const int rem = mb - hn * tpi;
+    const int tyi = rem / a.tilesX;
+    oy0 = tyi * TH;
+    ox0 = (rem - tyi * a.tilesX) * 16;
+  }
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
   const int K = a.KH * a.KW * a.Cin;
@@ -108,7 +127,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
   const unsigned ohw = (unsigned)(a.OHg * a.OWg);
   constexpr bool pointwise = PW;
 #pragma unroll
-  for (int i = 0; i < AR; ++i) {
+  for (int i = 0; i < (HALO ? 0 : AR); ++i) {
     const long long m = (long long)mb * BM + r0 + 64 * i;
     if (m < a.M) {
       if (pointwise) {
@@ -136,11 +155,37 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
 
   int kh = 0, kw = 0, c0 = 0;  // position of the NEXT stage to issue
   const int KT = K / BK;
-  constexpr int NL = AR + BR;  // LDS-DMA instructions per thread per stage
+  constexpr int NL = HALO ? BR : AR + BR;  // LDS-DMA instructions per thread per stage (HALO: the halo's own, once per
+                                           // nine stages, only make the counted waits below conservative)
   const int widu = __builtin_amdgcn_readfirstlane(wid);
   const T* zsrc = reinterpret_cast<const T*>(g_zero64);
 
   auto issue_stage = [&](int kt, int slot) {
+    if constexpr (HALO) {
+      // kh = chunk counter, kw = tap counter of the NEXT stage to issue
+      if (kw == 0) {
+        char* hb = smem + NSTAGE * STAGE + (kh & 1) * HSLOT + widu * 1024;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+          const int hp = r0 + 64 * i;                 // pixel slot of this lane
+          const int hy = hp / 24, hx = hp - hy * 24;
+          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+          const bool ok = hx < 18 && hy < TH + 2 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+          const int sc = (tid & 3) ^ (((hp >> 2) & 1) << 1);   // slot chunk (tid&3) holds source chunk sc
+          const T* src = ok ? x + (((long long)hn * a.IH + iy) * a.IW + ix) * a.Cin + kh * BK + sc * EPC : zsrc;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(hb + i * 4096), 16, 0, 0);
+        }
+      }
+      char* sb = smem + slot * STAGE + widu * 1024;
+      const long long boff = (long long)kw * a.Cin + kh * BK;
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + boff),
+                                         (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
+      if (++kw == 9) { kw = 0; ++kh; }
+      return;
+    }
     const long long tapoff = PW ? (long long)kt * BK : ((long long)kh * a.IW + kw) * a.Cin + c0;
     char* sa = smem + slot * STAGE + widu * 1024;
     char* sb = sa + BM * 64;
@@ -174,6 +219,16 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
   const int frow = lane & 15;
   const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) << 1)) << 4);
 
+  // HALO: per-lane fragment offsets inside a halo row for kw = 0, 1, 2 (24 slots per row keep bit 2 of the pixel
+  // slot, which the swizzle uses, a function of tx + kw alone); ctap / cchunk = tap and chunk of the stage being
+  // multiplied
+  int hoff[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int px = frow + q;
+    hoff[q] = px * 64 + (((lane >> 4) ^ (((px >> 2) & 1) << 1)) << 4);
+  }
+  int ctap = 0, cchunk = 0;
   const int pre = KT < NSTAGE - 1 ? KT : NSTAGE - 1;
   for (int s = 0; s < pre; ++s) issue_stage(s, s);
 
@@ -191,11 +246,21 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
     // everyone has finished reading slot (kt-1)%NSTAGE -> refill it with stage kt+NSTAGE-1
     if (kt + NSTAGE - 1 < KT) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
     const int slot = kt % NSTAGE;
-    const char* sa = smem + slot * STAGE + (wm * WM) * 64 + foff;
-    const char* sb = smem + slot * STAGE + BM * 64 + (wn * WN) * 64 + foff;
+    const char* sa;
+    const char* sb;
+    if constexpr (HALO) {
+      const int ckh = ctap / 3, ckw = ctap - ckh * 3;
+      const int ho = ckw == 0 ? hoff[0] : (ckw == 1 ? hoff[1] : hoff[2]);
+      sa = smem + NSTAGE * STAGE + (cchunk & 1) * HSLOT + (wm * (WM / 16) + ckh) * (24 * 64) + ho;
+      sb = smem + slot * STAGE + (wn * WN) * 64 + foff;
+      if (++ctap == 9) { ctap = 0; ++cchunk; }
+    } else {
+      sa = smem + slot * STAGE + (wm * WM) * 64 + foff;
+      sb = smem + slot * STAGE + BM * 64 + (wn * WN) * 64 + foff;
+    }
     frag_t af[TM], bfr[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * 16 * 64);
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * (HALO ? 24 * 64 : 16 * 64));
 #pragma unroll
     for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
 #pragma unroll
@@ -204,6 +269,23 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
       for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
   }
   __syncthreads();  // all DMA retired (vmcnt(0) above); the ring is now reused as the C tile
+  if constexpr (HALO) {
+    // patch rows / columns outside the image hold sums over real neighbours: zero them so that neither the
+    // statistics nor anything else sees them (their stores are skipped below)
+    if (oy0 + TH > a.OH || ox0 + 16 > a.OW) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bool rowok = oy0 + wm * (WM / 16) + i < a.OH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rowok && (ox0 + (lane >> 4) * 4 + r < a.OW);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (!ok) acc[i][j][r] = 0.f;
+        }
+      }
+    }
+  }
 
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
@@ -321,7 +403,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
         const int row = tid / CPR + it * RPI;
         long long ooff = off0 + it * ostep;
         ok[b] = true;
-        if (!full) {
+        if constexpr (HALO) {
+          const int R = ph * CROWS + row;
+          const int oy = oy0 + (R >> 4), ox = ox0 + (R & 15);
+          ok[b] = oy < a.OH && ox < a.OW;
+          ooff = (((long long)hn * a.OH + oy) * a.OW + ox) * a.Cout + nb * BN + chf * EPC;
+        } else if (!full) {
           const long long m = (long long)mb * BM + ph * CROWS + row;
           ok[b] = m < a.M;
           long long opix = m;
@@ -395,7 +482,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
     const int row = tid / CPR + it * RPI, ch = chf;
     long long opix;
     long long ooff_fast = off0 + it * ostep;
-    if (!full) {
+    if constexpr (HALO) {
+      const int R = ph * CROWS + row;
+      const int oy = oy0 + (R >> 4), ox = ox0 + (R & 15);
+      if (oy >= a.OH || ox >= a.OW) continue;
+      ooff_fast = (((long long)hn * a.OH + oy) * a.OW + ox) * a.Cout + nb * BN + ch * EPC;
+    } else if (!full) {
       const long long m = (long long)mb * BM + ph * CROWS + row;
       if (m >= a.M) continue;
       opix = m;
@@ -484,20 +576,20 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
   }
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW>
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false>
 static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int stage = NSTAGE * (BM + BN) * 64;
+  constexpr int stage = HALO ? NSTAGE * BN * 64 + 2 * (((BM / 16 + 2) * 24 + 63) / 64) * 4096 : NSTAGE * (BM + BN) * 64;
   constexpr int epi = (BM < 128 ? BM : 128) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
   constexpr int lds = stage > epi ? stage : epi;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
   const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -571,6 +663,56 @@ static int choose_bm(const maai_conv_desc* d, int dtype) {
   return (d->KH * d->KW * d->Cin >= 512 && tiles >= 512) ? 256 : 128;
 }
 
+// Halo-staged tiles (HALO kernels) for the 3x3 stride-1 same-size layers whose planes the 16x16 patches cover
+// without much waste.  MAAI_CONV_HALO = 0 | 1 overrides the shape rule (read per call, for tests and A/B runs).
+struct ConvPlan {
+  int bm;
+  bool halo;
+  int tilesX, tilesY;
+  long long nMB;
+};
+static ConvPlan conv_plan(const maai_conv_desc* d, int dtype) {
+  ConvPlan p;
+  p.bm = choose_bm(d, dtype);
+  p.halo = false;
+  p.tilesX = p.tilesY = 0;
+  const long long M = (long long)d->N * d->OHg * d->OWg;
+  const bool shape_ok = dtype == MAAI_BF16 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+                        d->OHg == d->IH && d->OWg == d->IW && d->OH == d->OHg && d->OW == d->OWg && d->out_stride == 1 &&
+                        d->out_off_h == 0 && d->out_off_w == 0 && d->Cin % 32 == 0;
+  if (shape_ok) {
+    const char* e = getenv("MAAI_CONV_HALO");
+    const int forced = e ? atoi(e) : -1;
+    const int tx = (d->OW + 15) / 16, ty = (d->OH + 15) / 16;
+    const long long tiles = (long long)d->N * tx * ty * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
+    const double cover = (double)d->OH * d->OW / ((double)tx * 16 * ty * 16);
+    // measured inside bench.py (B = 256, per launch): C64@224 1.72 -> 1.38 ms, C128@112 1.03 -> 0.88 ms; planes the
+    // 16x16 patches cover badly lose it again (C256@56, 77 % cover: 0.91 -> 0.96 ms), so those stay row-staged
+    const bool pays = cover >= 0.9;
+    if (forced == 1 || (forced != 0 && pays && tiles >= 512)) {
+      p.halo = true;
+      p.bm = 256;
+      p.tilesX = tx;
+      p.tilesY = ty;
+      p.nMB = (long long)d->N * tx * ty;
+      return p;
+    }
+  }
+  p.nMB = (M + p.bm - 1) / p.bm;
+  return p;
+}
+
+template <int BN>
+static int launch_halo(const ConvArgs& a, hipStream_t st) {
+  if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_conv_p<bf16_t, 256, BN, 3, 6, false, true>(a, st);
+  if (a.emode != 0) {
+    maai_set_error("conv2d_igemm: BN epilogues are for pointwise layers");
+    return MAAI_ERR_UNSUPPORTED;
+  }
+  if (a.accumulate || a.mask) return launch_conv_p<bf16_t, 256, BN, 3, 5, false, true>(a, st);
+  return launch_conv_p<bf16_t, 256, BN, 3, 0, false, true>(a, st);
+}
+
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                  const void* relu_mask, int dtype, void* stream) {
   return maai_conv2d_igemm_fused(d, x, w, y, stats_partial, relu_mask, nullptr, dtype, stream);
@@ -626,8 +768,12 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
     return maai_pw_conv_launch(p, emode, st);
   }
-  const int bm = choose_bm(d, dtype);
-  a.nMB = (int)((a.M + bm - 1) / bm);
+  const ConvPlan plan = conv_plan(d, dtype);
+  const int bm = plan.bm;
+  a.nMB = (int)plan.nMB;
+  a.tilesX = plan.tilesX;
+  a.tilesY = plan.tilesY;
+  if (plan.halo) return d->Cout % 128 == 0 ? (a.nNB = d->Cout / 128, launch_halo<128>(a, st)) : (a.nNB = d->Cout / 64, launch_halo<64>(a, st));
   static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
   const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);
@@ -643,7 +789,5 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
 /* rows of the statistics slab: one per M-tile of the kernel maai_conv2d_igemm picks for (d, dtype) */
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {
   if (!d) return 0;
-  const long long M = (long long)d->N * d->OHg * d->OWg;
-  const int bm = choose_bm(d, dtype);
-  return (M + bm - 1) / bm;
+  return conv_plan(d, dtype).nMB;
 }

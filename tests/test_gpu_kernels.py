@@ -70,6 +70,54 @@ def conv_bm(request):
         os.environ["MAAI_CONV_BM"] = old
 
 
+@pytest.fixture(params=["0", "1"], ids=["rows", "halo"])
+def conv_halo(request):
+    """Halo-staged 16x16 patches for 3x3 stride-1 layers (normally chosen by shape; forced on / off here)."""
+    old = os.environ.get("MAAI_CONV_HALO")
+    os.environ["MAAI_CONV_HALO"] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop("MAAI_CONV_HALO", None)
+    else:
+        os.environ["MAAI_CONV_HALO"] = old
+
+
+@pytest.mark.parametrize("case", [(2, 64, 30, 30, 64), (1, 64, 16, 16, 128), (3, 128, 13, 11, 128), (2, 32, 40, 24, 192),
+                                  (1, 256, 33, 17, 256), (5, 64, 9, 7, 64)])
+def test_conv3x3_halo_patches(K, case):
+    """The halo-staged kernel on full, ragged and tiny planes: output and BatchNorm partial sums against fp64,
+    and bit-for-bit against the row-staged kernel on integer data (exact arithmetic in any summation order)."""
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(77 + h)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    xi = torch.randint(-3, 4, (n, cin, h, w), generator=g).float()
+    wi = torch.randint(-2, 3, (cout, cin, 3, 3), generator=g).float()
+    got = {}
+    old = os.environ.get("MAAI_CONV_HALO")
+    try:
+        for mode in ("0", "1"):
+            os.environ["MAAI_CONV_HALO"] = mode
+            y, part = K.conv2d(nhwc(x, torch.bfloat16), khwc(wt, torch.bfloat16), 1, 1, 1, stats=True)
+            yi = K.conv2d(nhwc(xi, torch.bfloat16), khwc(wi, torch.bfloat16), 1, 1, 1)
+            torch.cuda.synchronize()
+            got[mode] = (from_nhwc(y), K.reduce_partials(part).cpu(), from_nhwc(yi))
+    finally:
+        if old is None:
+            os.environ.pop("MAAI_CONV_HALO", None)
+        else:
+            os.environ["MAAI_CONV_HALO"] = old
+    m = n * h * w
+    for mode in ("0", "1"):
+        y, sums, yi = got[mode]
+        np.testing.assert_allclose(y.numpy(), ref.float().numpy(), **tol(torch.bfloat16))
+        np.testing.assert_allclose(sums[:cout].numpy(), ref.sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=2e-3 * m ** 0.5)
+        np.testing.assert_allclose(sums[cout:].numpy(), (ref * ref).sum(dim=(0, 2, 3)).numpy(), rtol=2e-4, atol=1e-3)
+        assert torch.equal(yi, rb(F.conv2d(xi, wi, None, 1, 1)))
+    assert torch.equal(got["0"][2], got["1"][2])
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_and_stats(K, case, dtype, conv_bm):
@@ -400,7 +448,7 @@ def test_augment_bit_exact(K):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_conv_relu_mask_epilogue(K, dtype, conv_bm):
+def test_conv_relu_mask_epilogue(K, dtype, conv_bm, conv_halo):
     """y = conv(x, w) * (mask > 0), alone and combined with accumulate + strided scatter."""
     g = torch.Generator().manual_seed(21)
     x = torch.randn(2, 64, 9, 9, generator=g)
@@ -426,7 +474,7 @@ def test_conv_relu_mask_epilogue(K, dtype, conv_bm):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("variant", ["mask_tensor", "mask_from_y", "mask_bits", "no_mask"])
 @pytest.mark.parametrize("case", [(2, 64, 9, 9, 128, 3, False), (3, 256, 7, 5, 64, 1, True), (2, 128, 8, 8, 64, 3, True), (1, 64, 40, 40, 192, 3, False)])
-def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm):
+def test_conv_store_reduce_epilogue(K, case, variant, dtype, conv_bm, conv_halo):
     """MAAI_EPI_DGRAD_REDUCE: the stored gradient g equals the plain (accumulate + mask) epilogue's bit for bit,
     and the partial sums equal those of the separate reduction pass over the stored g (sum g, sum g*(y - mean))."""
     n, cin, h, w, cout, k, acc = case
