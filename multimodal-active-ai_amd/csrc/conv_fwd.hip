@@ -656,8 +656,15 @@ static int choose_bm(const maai_conv_desc* d, int dtype) {
   const char* e = getenv("MAAI_CONV_BM");
   const int forced = e ? atoi(e) : 0;
   if (forced == 64) return 64;
-  if (forced == 128 || dtype != MAAI_BF16 || d->KH * d->KW == 1) return 128;
-  if (forced == 256) return 256;
+  if (forced == 128 || dtype != MAAI_BF16) return 128;
+  if (forced == 256 && (d->KH * d->KW > 1 || d->Cout % 128 == 0)) return 256;
+  // pointwise layers: only the channel-reducing ones (Cin >= 2 Cout, long K for few output columns) gain from the
+  // taller tile (scripts/conv_pw_ab.py, B = 256: 1024->256 693 -> 768, 2048->512 781 -> 881, 512->128 506 -> 537 TFLOP/s);
+  // the expanding, HBM-bound ones lose (64->256: 248 -> 208)
+  if (d->KH * d->KW == 1) {
+    const long long Mp = (long long)d->N * d->OHg * d->OWg;
+    return (d->Cout % 128 == 0 && d->Cin >= 2 * d->Cout && ((Mp + 255) / 256) * (d->Cout / 128) >= 512) ? 256 : 128;
+  }
   const long long M = (long long)d->N * d->OHg * d->OWg;
   const long long tiles = ((M + 255) / 256) * (d->Cout / (d->Cout % 128 == 0 ? 128 : 64));
   return (d->KH * d->KW * d->Cin >= 512 && tiles >= 512) ? 256 : 128;
