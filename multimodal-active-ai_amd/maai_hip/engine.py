@@ -164,12 +164,16 @@ class _Rec(object):
 # extra conv passes cost 92 ms, because the short-K conv workgroups are latency-serialised (launch, load wait,
 # MFMA, epilogue) rather than streaming at the HBM rate — net -3 %.  So the fused unit is OFF by default (0) until
 # the pointwise kernel is persistent; the kernels and their bit-exactness tests stay in place.
-_FUSE = {"max_cin": int(os.environ.get("MAAI_FUSE_MAX_CIN", "0"))}
+_FUSE = {"max_cin": int(os.environ.get("MAAI_FUSE_MAX_CIN", "0")),
+         # the same recompute trade for forward passes that keep nothing for a backward (the no-grad view of the
+         # SimCLR step, evaluation): only the two forward conv passes are paid, none of the backward ones
+         "nograd_max_cin": int(os.environ.get("MAAI_FUSE_NOGRAD_MAX_CIN", "0"))}
 
 
-def _fusable(conv, form):
+def _fusable(conv, form, keep=True):
+    lim = _FUSE["max_cin"] if keep else max(_FUSE["max_cin"], _FUSE["nograd_max_cin"])
     return (form == "fwd" and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
-            and conv.in_channels <= _FUSE["max_cin"] and conv.out_channels >= 4 * conv.in_channels)
+            and conv.in_channels <= lim and conv.out_channels >= 4 * conv.in_channels)
 
 
 def _sync_world(bn):
@@ -201,7 +205,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
     training = bn.training or (bn.running_mean is None)
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
-    fused = _fusable(conv, form) and not defer and branch is None
+    fused = _fusable(conv, form, keep) and not defer and branch is None
     y = None
     if training:
         if fused:
