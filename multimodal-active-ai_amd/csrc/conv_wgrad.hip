@@ -386,6 +386,192 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   return MAAI_OK;
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 same-size layers, bf16: patch-staged weight gradient.
+// The ring kernel above re-stages, for every (tap, ci) column tile, dY and a shifted copy of x: 3 LDS-DMA
+// instructions per 8 MFMAs per wave, 5-9x the algorithmic bytes through L2 -> 360-620 TFLOP/s.  Here a workgroup
+// (6 waves) owns a 64(co) x 9(taps) x 64(ci) block of dW and walks 8x16 patches of output pixels: per patch it
+// stages dY [128 px][64 co] and the 10x18 input halo [10 x 24 slots][64 ci] ONCE (46 KB, 46 DMA instructions)
+// and every tap reads the halo at a shifted pixel address with transposed reads — 576 MFMAs per 46 DMA
+// instructions.  Wave (h, kh): output-channel half h (two 16-row tiles), kernel row kh, all three kw, all four ci
+// tiles = 24 accumulator tiles.  K-step = two patch rows (32 pixels): row r of the step is pixel (2s + r/16, r%16).
+// 128-byte rows, swizzle chunk ^ 2*((row>>1)&3): eight consecutive rows fill the 256-byte bank row for
+// ds_read_b64_tr_b16 at ANY starting row, and 24-slot halo rows keep it a function of (x + kw) alone.
+// Single-buffered (two workgroups per CU overlap each other's load and multiply phases); fp32 atomics at the end.
+// ---------------------------------------------------------------------------
+struct WgradPatchArgs {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int N, H, W, Cin, Cout;
+  int tilesX, tilesY;
+  int nCoB, nCiB;
+  long long npatch, per_split;
+};
+
+__global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a) {
+  constexpr int TH = 8, HW = 24, RB = 128;            // patch rows, halo slots per row, bytes per pixel row (64 ch)
+  constexpr int YB = TH * 16 * RB;                    // dY tile bytes (16 KB)
+  constexpr int NIY = YB / 1024, NIH = (TH + 2) * HW * RB / 1024;  // wave-wide DMA instructions: 16 + 30
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ybuf = smem;
+  char* hbuf = smem + YB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  const int half = widu / 3, kh = widu - half * 3;
+  const int ntiles = a.nCoB * a.nCiB;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int cob = tile / a.nCiB, cib = tile - cob * a.nCiB;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
+  const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_wzero64);
+  const long long p_begin = (long long)split * a.per_split;
+  long long p_end = p_begin + a.per_split;
+  if (p_end > a.npatch) p_end = a.npatch;
+
+  f32x4 acc[2][3][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, p = li & 3;
+  const int r0 = 4 * g + q;  // this lane's row inside a 16-row half step
+  // transposed-read offsets: A (dY, rows linear), B (halo, three kw shifts x four ci tiles)
+  // (the ci-tile index j only flips bits 5-6 of the offset: base + (swz ^ (j << 5)), two registers per shift)
+  int offA[2], baseB[3], swzB[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = 2 * (2 * half + i) + (p >> 1);
+    offA[i] = r0 * RB + ((c ^ (((r0 >> 1) & 3) << 1)) << 4) + ((p & 1) << 3);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int hr = r0 + k;  // slot x-index of this lane's pixel at shift kw = k (slot 0 is column -1)
+    baseB[k] = hr * RB + ((p & 1) << 3);
+    swzB[k] = ((p >> 1) ^ (((hr >> 1) & 3) << 1)) << 4;
+  }
+  const int tpi = a.tilesX * a.tilesY;
+  const int drow = lane >> 3, dch = lane & 7;  // DMA: 8 lanes per 128-byte row
+
+  for (long long pt = p_begin; pt < p_end; ++pt) {
+    const int n = (int)(pt / tpi);
+    const int rem = (int)(pt - (long long)n * tpi);
+    const int tyi = rem / a.tilesX;
+    const int oy0 = tyi * TH, ox0 = (rem - tyi * a.tilesX) * 16;
+    __syncthreads();  // everyone is done multiplying the previous patch
+#pragma unroll
+    for (int i = 0; i < (NIY + NIH + 5) / 6; ++i) {
+      const int qi = widu + 6 * i;  // wave-uniform instruction index
+      if (qi < NIY) {
+        const int row = qi * 8 + drow;  // pixel of the patch
+        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+        const int sc = dch ^ (((row >> 1) & 3) << 1);
+        const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + sc * 8 : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
+      } else if (qi < NIY + NIH) {
+        const int hp = (qi - NIY) * 8 + drow;  // halo slot
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+        const int sc = dch ^ (((hp >> 1) & 3) << 1);
+        const bool ok = hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const bf16_t* src = ok ? x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + sc * 8 : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TH / 2; ++s) {
+      bf16x8 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* base = ybuf + s * 32 * RB + offA[i];
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(base + 16 * RB));
+        af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      const char* hrow = hbuf + (2 * s + kh) * (HW * RB);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        bf16x8 bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ob = baseB[k] + (swzB[k] ^ (j << 5));
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(hrow + ob));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(hrow + HW * RB + ob));
+          bfr[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][k][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next shift's fragment reads from being hoisted (register budget)
+      }
+    }
+  }
+  if (p_begin >= p_end) return;
+  // C layout: row (co) = 4g + r, column (ci) = li
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + (2 * half + i) * 16 + 4 * g + r;
+          const int ci = ci0 + j * 16 + li;
+          atomicAdd(a.dw + (((long long)co * 3 + kh) * 3 + k) * a.Cin + ci, acc[i][k][j][r]);
+        }
+}
+
+// MAAI_WGRAD_PATCH = 0 | 1 overrides the shape rule (read per call, for tests and A/B runs)
+static bool wgrad_patch_applies(const WgradArgs& a) {
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.IH == a.OH && a.IW == a.OW &&
+        a.Cin % 64 == 0 && a.Cout % 64 == 0))
+    return false;
+  const char* e = getenv("MAAI_WGRAD_PATCH");
+  const int forced = e ? atoi(e) : -1;
+  if (forced == 0) return false;
+  if (forced == 1) return true;
+  const int tx = (a.OW + 15) / 16, ty = (a.OH + 7) / 8;
+  const double cover = (double)a.OH * a.OW / ((double)tx * 16 * ty * 8);
+  return cover >= 0.85 && (long long)a.N * tx * ty >= 2048;
+}
+
+static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
+  WgradPatchArgs a;
+  a.x = w.x; a.dy = w.dy; a.dw = w.dw;
+  a.N = w.N; a.H = w.OH; a.W = w.OW; a.Cin = w.Cin; a.Cout = w.Cout;
+  a.tilesX = (w.OW + 15) / 16;
+  a.tilesY = (w.OH + 7) / 8;
+  a.nCoB = w.Cout / 64;
+  a.nCiB = w.Cin / 64;
+  a.npatch = (long long)w.N * a.tilesX * a.tilesY;
+  const long long tiles = (long long)a.nCoB * a.nCiB;
+  if (target <= 0) target = 512;  // two 6-wave workgroups per CU
+  long long split = (target + tiles - 1) / tiles;
+  if (split > a.npatch) split = a.npatch;
+  if (split < 1) split = 1;
+  a.per_split = (a.npatch + split - 1) / split;
+  split = (a.npatch + a.per_split - 1) / a.per_split;
+  constexpr int lds = 8 * 16 * 128 + 10 * 24 * 128;  // 16 KB + 30 KB
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad3x3_patch_kernel, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 // Tile choice: every (co-tile, column-tile) pair streams all pixels, so operand traffic is
 // M * (BCO + BCN) * 2 B * (Cout/BCO) * (KN/BCN).  Measured with FETCH_SIZE, the 128x128 tile moved 2.6x the
 // algorithmic bytes (profiles/r01_pmc_traffic_b256.json) and ran at the fabric rate, not the MFMA rate;
@@ -457,6 +643,9 @@ extern "C" int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, c
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OH = d->OH; a.OW = d->OW;
   a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY")) return dispatch_wgrad_bf16(a, st, target_blocks);
+  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY")) {
+    if (wgrad_patch_applies(a)) return launch_wgrad_patch(a, st, target_blocks > 0 ? target_blocks / 3 : 0);
+    return dispatch_wgrad_bf16(a, st, target_blocks);
+  }
   return dtype == MAAI_BF16 ? dispatch_wgrad<bf16_t>(a, st) : dispatch_wgrad<float>(a, st);
 }

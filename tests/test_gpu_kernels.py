@@ -212,6 +212,37 @@ def test_wgrad_exact_integer_layout(K):
         assert torch.equal(dw.cpu().permute(0, 3, 1, 2), wt.grad)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 30, 30, 64), (1, 128, 16, 16, 64), (3, 64, 13, 11, 128), (2, 128, 40, 24, 192),
+                                  (1, 64, 8, 16, 64), (5, 192, 9, 7, 64)])
+def test_wgrad3x3_patch_kernel(K, case):
+    """The patch-staged 3x3 weight gradient (normally chosen by shape, forced on here): against autograd in fp64
+    on random bf16 data, and bit-for-bit on integer data (exact in any order) — full, ragged and tiny planes,
+    several (co, ci) tiles, more splits than patches."""
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(55 + h + cin)
+    x, dy = rb(torch.randn(n, cin, h, w, generator=g)), rb(torch.randn(n, cout, h, w, generator=g))
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, 1, 1).backward(dy.double())
+    xi = torch.randint(-2, 3, (n, cin, h, w), generator=g).float()
+    dyi = torch.randint(-2, 3, (n, cout, h, w), generator=g).float()
+    wi = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(xi, wi, None, 1, 1).backward(dyi)
+    old = os.environ.get("MAAI_WGRAD_PATCH")
+    os.environ["MAAI_WGRAD_PATCH"] = "1"
+    try:
+        dw = K.conv2d_wgrad(nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16), 3, 3, 1, 1, 1)
+        dwi = K.conv2d_wgrad(nhwc(xi, torch.bfloat16), nhwc(dyi, torch.bfloat16), 3, 3, 1, 1, 1)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            os.environ.pop("MAAI_WGRAD_PATCH", None)
+        else:
+            os.environ["MAAI_WGRAD_PATCH"] = old
+    scale = wt.grad.abs().max().item()
+    np.testing.assert_allclose(dw.cpu().permute(0, 3, 1, 2).numpy(), wt.grad.float().numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
+    assert torch.equal(dwi.cpu().permute(0, 3, 1, 2), wi.grad)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("shape", [(4, 64, 15, 15), (2, 256, 8, 8), (3, 2048, 4, 4), (16, 1024, 1, 1)])
 @pytest.mark.parametrize("res", [False, True])
