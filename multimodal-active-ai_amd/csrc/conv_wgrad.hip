@@ -457,31 +457,69 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
   const int tpi = a.tilesX * a.tilesY;
   const int drow = lane >> 3, dch = lane & 7;  // DMA: 8 lanes per 128-byte row
 
+  // DMA sources.  Interior patches (all but the plane's border ring) need no per-lane decode: each of this wave's
+  // instructions reads patch base + a per-lane offset fixed for the whole kernel (pad slots -> the zero page).
+  constexpr int NDI = (NIY + NIH + 5) / 6;
+  int rel[NDI];
+  unsigned padmask = 0;
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) {
+    const int qi = widu + 6 * i;
+    rel[i] = 0;
+    if (qi < NIY) {
+      const int row = qi * 8 + drow;
+      rel[i] = ((row >> 4) * a.W + (row & 15)) * a.Cout + co0 + (dch ^ (((row >> 1) & 3) << 1)) * 8;
+    } else if (qi < NIY + NIH) {
+      const int hp = (qi - NIY) * 8 + drow;
+      const int hy = hp / HW, hx = hp - hy * HW;
+      rel[i] = ((hy - 1) * a.W + (hx - 1)) * a.Cin + ci0 + (dch ^ (((hp >> 1) & 3) << 1)) * 8;
+      if (hx >= 18) padmask |= 1u << i;
+    }
+  }
+
   for (long long pt = p_begin; pt < p_end; ++pt) {
     const int n = (int)(pt / tpi);
     const int rem = (int)(pt - (long long)n * tpi);
     const int tyi = rem / a.tilesX;
     const int oy0 = tyi * TH, ox0 = (rem - tyi * a.tilesX) * 16;
     __syncthreads();  // everyone is done multiplying the previous patch
+    if (oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + 17 <= a.W) {
+      const long long pix0 = ((long long)n * a.H + oy0) * a.W + ox0;
+      const bf16_t* by = dy + pix0 * a.Cout;
+      const bf16_t* bx = x + pix0 * a.Cin;
 #pragma unroll
-    for (int i = 0; i < (NIY + NIH + 5) / 6; ++i) {
-      const int qi = widu + 6 * i;  // wave-uniform instruction index
-      if (qi < NIY) {
-        const int row = qi * 8 + drow;  // pixel of the patch
-        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-        const int sc = dch ^ (((row >> 1) & 3) << 1);
-        const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + sc * 8 : zsrc;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
-      } else if (qi < NIY + NIH) {
-        const int hp = (qi - NIY) * 8 + drow;  // halo slot
-        const int hy = hp / HW, hx = hp - hy * HW;
-        const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-        const int sc = dch ^ (((hp >> 1) & 3) << 1);
-        const bool ok = hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const bf16_t* src = ok ? x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + sc * 8 : zsrc;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+      for (int i = 0; i < NDI; ++i) {
+        const int qi = widu + 6 * i;
+        if (qi < NIY) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(by + rel[i]),
+                                           (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
+        } else if (qi < NIY + NIH) {
+          const bf16_t* src = ((padmask >> i) & 1u) ? zsrc : bx + rel[i];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NDI; ++i) {
+        const int qi = widu + 6 * i;  // wave-uniform instruction index
+        if (qi < NIY) {
+          const int row = qi * 8 + drow;  // pixel of the patch
+          const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+          const int sc = dch ^ (((row >> 1) & 3) << 1);
+          const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + sc * 8 : zsrc;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
+        } else if (qi < NIY + NIH) {
+          const int hp = (qi - NIY) * 8 + drow;  // halo slot
+          const int hy = hp / HW, hx = hp - hy * HW;
+          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+          const int sc = dch ^ (((hp >> 1) & 3) << 1);
+          const bool ok = hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+          const bf16_t* src = ok ? x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + sc * 8 : zsrc;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
