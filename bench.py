@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
     ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
+    ap.add_argument("--recompute", action="store_true",
+                    help="block recompute in the backward (fits --batch 512 = global 4096 on 8 GPUs in 288 GB; one extra forward)")
     return ap.parse_args()
 
 
@@ -150,6 +152,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    if args.recompute:
+        from maai_hip import engine
+        engine.set_recompute(True)
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
 
@@ -242,7 +247,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SimCLR %s 3x%dx%d (reference stem), per-GPU batch %d, two-view step: aug + fwd(view1, no grad) + "
                                    "fwd(view2) + NT-Xent tau=%g + bwd + Adam" % (args.arch, args.img, args.img, args.batch, args.temperature),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.item())},
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.item()),
+                       "recompute": bool(args.recompute), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -192,11 +192,13 @@ def _check_conv(conv):
 _DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
 
 
-def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None):
+def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None):
     """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).
     ``defer``: stop after the statistics — returns ((y, scale, shift), rec) with rec.out = None, for a shortcut
     branch whose normalisation is applied by the unit it is added to; ``branch`` = such a (y2, scale2, shift2)
-    triple, applied and added in this unit's single BN pass (maai_bn_act_fwd2) in place of ``residual``."""
+    triple, applied and added in this unit's single BN pass (maai_bn_act_fwd2) in place of ``residual``.
+    ``given``: a record of an earlier run of this very unit (block recompute): its statistics are reused, the
+    convolution runs without a statistics epilogue and the running buffers are left alone."""
     _check_conv(conv)
     k = conv.kernel_size[0]
     stride, pad = conv.stride[0], conv.padding[0]
@@ -205,9 +207,13 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
     training = bn.training or (bn.running_mean is None)
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
-    fused = _fusable(conv, form, keep) and not defer and branch is None
+    fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
     y = None
-    if training:
+    if given is not None:
+        training = given.training
+        y = K.conv2d(x, wq, stride, pad, pad_w)
+        mean, invstd, scale, shift, count, world = given.mean, given.invstd, given.scale, given.shift, given.count, given.world
+    elif training:
         if fused:
             part = K.conv2d_stats_only(x, wq)
             c = wq.shape[0]
@@ -458,6 +464,49 @@ def stem_input(x, conv1, dtype):
     return K.nchw_to_nhwc(x, cpad, dtype), w_fwd(conv1.weight, dtype, cpad), "fwd"
 
 
+# Block recompute (MAAI_RECOMPUTE=1 / set_recompute): the forward keeps, per residual block, only its input and the
+# per-unit BatchNorm statistics; the backward re-runs the block's forward from them (same kernels, no statistics
+# epilogues, bit-identical tensors) just before differentiating it.  Activation memory drops from ~12 to ~4 C-wide
+# tensors per block — what lets 512 images per GPU (global batch 4096 on 8 GPUs, BASELINE configs[2]) fit in 288 GB —
+# for one extra forward of the differentiated view.
+_RECOMPUTE = {"enabled": os.environ.get("MAAI_RECOMPUTE", "0") == "1"}
+
+
+def set_recompute(flag):
+    _RECOMPUTE["enabled"] = bool(flag)
+
+
+def _lighten(r):
+    if r is not None:
+        r.x = r.y = r.out = r.bits = None
+    return r
+
+
+def _block_fwd(blk, xin, dtype, keep, given=None):
+    """One residual block (resnet.py:59-77 / :113-135).  Returns (out, (r1, r2, r3, rd))."""
+    g1, g2, g3, gd = given if given is not None else (None, None, None, None)
+    if hasattr(blk, "conv3"):  # Bottleneck
+        o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1)
+        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2)
+        last_conv, last_bn = blk.conv3, blk.bn3
+    else:  # BasicBlock
+        o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1)
+        r2 = None
+        last_conv, last_bn = blk.conv2, blk.bn2
+    rd = None
+    if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
+        # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored
+        br, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True, given=gd)
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br, given=g3)
+    else:
+        if blk.downsample is not None:
+            idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, given=gd)
+        else:
+            idn = xin
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep, given=g3)
+    return out, (r1, r2, r3, rd)
+
+
 def backbone_fwd(resnet, x, dtype, keep):
     """resnet.py:226-240.  Returns (NHWC feature map, tape)."""
     xs, wq, form = stem_input(x, resnet.conv1, dtype)
@@ -467,28 +516,14 @@ def backbone_fwd(resnet, x, dtype, keep):
     out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form)
     K.FLOPS_SCALE[0] = 1.0
     tape.append(("stem", r))
+    ckpt = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
     for blk in _blocks(resnet):
         xin = out
-        if hasattr(blk, "conv3"):  # Bottleneck (resnet.py:113-135)
-            o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep)
-            o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep)
-            last_conv, last_bn = blk.conv3, blk.bn3
-        else:  # BasicBlock (resnet.py:59-77)
-            o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep)
-            r2 = None
-            last_conv, last_bn = blk.conv2, blk.bn2
-        rd = None
-        if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
-            # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored
-            br, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True)
-            out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br)
+        out, recs = _block_fwd(blk, xin, dtype, keep)
+        if ckpt:
+            tape.append(("ckpt", blk, xin, tuple(_lighten(r) for r in recs), out))
         else:
-            if blk.downsample is not None:
-                idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep)
-            else:
-                idn = xin
-            out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep)
-        tape.append(("block", r1, r2, r3, rd))
+            tape.append(("block",) + recs)
     return out, tape
 
 
@@ -532,7 +567,8 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
 
 def backbone_bwd(tape, dout, grads, dtype):
     """``dout``: gradient wrt the layer4 map, NOT yet masked."""
-    dout = relu_mask_grad(dout, tape[-1][3].out if tape[-1][0] == "block" else tape[-1][1].out)
+    last = tape[-1]
+    dout = relu_mask_grad(dout, last[4] if last[0] == "ckpt" else (last[3].out if last[0] == "block" else last[1].out))
     sums = None
     for i in range(len(tape) - 1, -1, -1):
         entry = tape[i]
@@ -542,8 +578,17 @@ def backbone_bwd(tape, dout, grads, dtype):
             unit_bwd(r, dout, grads, dtype, need_dx=False, presums=sums)
             K.FLOPS_SCALE[0] = 1.0
             return
+        if entry[0] == "ckpt":
+            # rebuild this block's records from its input and the saved statistics, differentiate, drop them; the
+            # block below is not materialised yet, so its BN-backward sums cannot ride this block's last epilogue
+            _, blk, xin, lights, _ = entry
+            _, recs = _block_fwd(blk, xin, dtype, True, given=lights)
+            dout, sums = block_bwd(("block",) + recs, dout, grads, dtype, prev=None, presums=sums)
+            tape[i] = None
+            del recs
+            continue
         below = tape[i - 1]
-        prev = below[1] if below[0] == "stem" else below[3]
+        prev = below[1] if below[0] == "stem" else (below[3] if below[0] == "block" else None)
         dout, sums = block_bwd(entry, dout, grads, dtype, prev=prev, presums=sums)
 
 

@@ -379,3 +379,46 @@ def test_backward_fusions_are_bit_identical(mods, prec):
         #  DESIGN.md "conditioning"; the per-block test above is the tight one)
         assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, n
         assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), n
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_block_recompute_matches_stored_activations(mods, prec):
+    """engine.set_recompute: the backward re-runs each block's forward from its saved input and BN statistics.
+    Same features bit for bit, far fewer bytes held between forward and backward, same gradients up to the
+    summation order of the BN-backward sums (those of a block's last unit no longer ride the epilogue above it),
+    and the running statistics are updated once, not twice."""
+    from maai_hip import engine
+    engine.set_precision(prec)
+    dtype = engine.compute_dtype()
+    x = _u8(6, (4, 3, 32, 32)).float().cuda()
+    res = {}
+    for tag in ("stored", "recompute"):
+        engine.set_recompute(tag == "recompute")
+        try:
+            m = _build(mods, "resnet50", 1, 2048 * 16, 4, (32, 32), 0.5)
+            m.train()
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            with torch.no_grad():
+                feat, tape = engine.backbone_fwd(m.f, x, dtype, keep=True)
+            torch.cuda.synchronize()
+            held = torch.cuda.memory_allocated() - base
+            g = torch.Generator().manual_seed(9)
+            dout = torch.randn(feat.shape, generator=g).to(dtype).cuda()
+            grads = {}
+            engine.backbone_bwd(tape, dout, grads, dtype)
+            torch.cuda.synchronize()
+            named = {n: grads[id(p)].float().cpu() for n, p in m.f.named_parameters() if id(p) in grads}
+            res[tag] = (feat.float().cpu(), named, held, m.f.layer2[0].bn2.running_var.clone().cpu(),
+                        int(m.f.layer2[0].bn2.num_batches_tracked))
+        finally:
+            engine.set_recompute(False)
+    assert torch.equal(res["stored"][0], res["recompute"][0])
+    assert res["recompute"][2] < 0.6 * res["stored"][2], (res["recompute"][2], res["stored"][2])
+    assert torch.equal(res["stored"][3], res["recompute"][3]) and res["stored"][4] == res["recompute"][4] == 1
+    assert res["stored"][1].keys() == res["recompute"][1].keys()
+    for n, gp in res["stored"][1].items():
+        gf = res["recompute"][1][n]
+        scale = gp.abs().max().item() + 1e-30
+        assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, n
+        assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), n
