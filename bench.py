@@ -251,6 +251,11 @@ def main():
                        "recompute": bool(args.recompute), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if args.arch == "resnet50" and args.img == 224:
+            # whole-step view: 4F = 512.1 GFLOP and 2.69 GB of ideal-fusion bf16 conv traffic per source image
+            out["step_roofline"] = {"gflop_per_image": 512.1, "ideal_GB_per_image": 2.69,
+                                    "frac_mfma": round(512.1e9 * value / world / (PEAK_BF16_TFLOPS * 1e12), 4),
+                                    "frac_hbm_ideal_fusion": round(2.69e9 * value / world / (PEAK_HBM_GBS * 1e9), 4)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

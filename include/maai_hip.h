@@ -219,6 +219,19 @@ int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, do
                    double eps, int step, float grad_scale, void* stream);
 int maai_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float weight_decay,
                   int first_step, void* stream);
+/* the same Adam update for every tensor of a parameter group in one launch (they share lr / betas / eps / step):
+ * slots[] (device memory) lists the tensors; block b of the launch updates 2048 consecutive elements of tensor
+ * block_slot[b] starting at element block_first[b] (both device arrays of nblocks entries, built by the host from
+ * the tensor sizes).  Identical arithmetic to maai_adam_step. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  long long n;
+} maai_adam_slot;
+int maai_adam_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                         double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------
  * Two-view augmentation replacing NVIDIA_DALI_Pipelines.py:444-480 for the

@@ -353,6 +353,40 @@ extern "C" int maai_adam_step(float* p, const float* g, float* m, float* v, long
   return MAAI_OK;
 }
 
+// all parameter tensors of a group in ONE launch: ~160 launches per step otherwise, each shorter than the time
+// the host needs to issue it.  slots[] and the block map live in device memory; block b updates 2048 elements of
+// tensor block_slot[b] starting at block_first[b].
+__global__ __launch_bounds__(256) void adam_multi_kernel(const maai_adam_slot* __restrict__ slots, const int* __restrict__ block_slot,
+                                                         const long long* __restrict__ block_first, float step_size, float beta1,
+                                                         float beta2, float omb1, float omb2, float eps, float inv_sqrt_bc2,
+                                                         float gscale) {
+  const maai_adam_slot s = slots[block_slot[blockIdx.x]];
+  const long long i0 = block_first[blockIdx.x];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long i = i0 + u * 256 + threadIdx.x;
+    if (i < s.n) {
+      const float gi = s.g[i] * gscale;
+      const float mi = beta1 * s.m[i] + omb1 * gi;
+      const float vi = beta2 * s.v[i] + omb2 * gi * gi;
+      s.m[i] = mi;
+      s.v[i] = vi;
+      s.p[i] = s.p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+  }
+}
+
+extern "C" int maai_adam_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                                    double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream) {
+  MAAI_CHECK_ARG(slots && block_slot && block_first && nblocks > 0 && step >= 1, "adam_step_multi: bad arguments");
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nblocks), dim3(256), 0, ST(stream), slots, block_slot, block_first, (float)(lr / bc1),
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)(1.0 / sqrt(bc2)),
+                     grad_scale);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                                                   long long n, float lr, float momentum, float wd, int first) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {

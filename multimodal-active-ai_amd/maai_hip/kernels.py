@@ -519,6 +519,42 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
                                int(step), float(grad_scale), _stream()), "maai_adam_step")
 
 
+class AdamMulti(object):
+    """One-launch Adam over a fixed list of fp32 tensors (maai_adam_step_multi).  The block map depends on the sizes
+    only and is built once; the slot table is re-uploaded per step because gradient tensors are new every step."""
+    CHUNK = 2048
+
+    def __init__(self, params, ms, vs):
+        import numpy as np
+        self.params, self.ms, self.vs = list(params), list(ms), list(vs)
+        _gpu(*self.params, *self.ms, *self.vs)
+        dev = self.params[0].device
+        slot, first = [], []
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            nb = (n + self.CHUNK - 1) // self.CHUNK
+            slot.append(np.full(nb, i, dtype=np.int32))
+            first.append(np.arange(nb, dtype=np.int64) * self.CHUNK)
+        self.block_slot = torch.from_numpy(np.concatenate(slot)).to(dev)
+        self.block_first = torch.from_numpy(np.concatenate(first)).to(dev)
+        self.nblocks = int(self.block_slot.numel())
+        self.table = np.zeros((len(self.params), 5), dtype=np.int64)   # maai_adam_slot: p, g, m, v, n
+        for i, (p, m, v) in enumerate(zip(self.params, self.ms, self.vs)):
+            self.table[i, 0], self.table[i, 2], self.table[i, 3], self.table[i, 4] = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+        self.table_dev = torch.empty((len(self.params), 5), dtype=torch.int64, device=dev)
+
+    def step(self, grads, lr, beta1, beta2, eps, step, grad_scale=1.0):
+        _gpu(*grads)
+        for i, g in enumerate(grads):
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.table[i, 4]:
+                raise MaaiError("adam_step_multi: gradients must be contiguous fp32 tensors of the parameter's size")
+            self.table[i, 1] = g.data_ptr()
+        self.table_dev.copy_(torch.from_numpy(self.table), non_blocking=False)
+        check(lib().maai_adam_step_multi(_p(self.table_dev), _p(self.block_slot), _p(self.block_first), self.nblocks, float(lr),
+                                         float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
+              "maai_adam_step_multi")
+
+
 def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step):
     _gpu(p, g, mom)
     check(lib().maai_sgd_step(_p(p), _p(g), _p(mom), p.numel(), float(lr), float(momentum), float(weight_decay),

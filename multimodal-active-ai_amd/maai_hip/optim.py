@@ -13,6 +13,7 @@ class HipAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._multi = {}   # per group: (key, kernels.AdamMulti) — one launch for all tensors of the group
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -20,8 +21,9 @@ class HipAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            live = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -31,8 +33,25 @@ class HipAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
+                live.append(p)
+            if not live:
+                continue
+            steps = {self.state[p]["step"] for p in live}
+            plain = all(p.dtype == torch.float32 and p.is_contiguous() for p in live)
+            if len(steps) == 1 and plain and len(live) > 1:
+                # every tensor of the group in one launch (the per-tensor launches are shorter than their issue time)
+                key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in live)
+                hit = self._multi.get(gi)
+                if hit is None or hit[0] != key:
+                    hit = (key, K.AdamMulti(live, [self.state[p]["exp_avg"] for p in live], [self.state[p]["exp_avg_sq"] for p in live]))
+                    self._multi[gi] = hit
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+                hit[1].step(grads, group["lr"], b1, b2, group["eps"], steps.pop())
+            else:
+                for p in live:
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    K.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"], st["step"])
         bump_weight_epoch()
         return loss
 

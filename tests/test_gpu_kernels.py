@@ -459,6 +459,31 @@ def test_adam_matches_oracle(K):
     np.testing.assert_allclose(qg.cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-6)
 
 
+def test_adam_multi_tensor_is_bit_identical(K):
+    """HipAdam updates all tensors of a group in one launch; same bits as the per-tensor kernel and as
+    torch.optim.Adam within rounding, over ragged sizes (1 element, non-multiples of the 2048-element chunk)."""
+    from maai_hip.optim import HipAdam
+    g = torch.Generator().manual_seed(12)
+    sizes = [(1,), (7, 3), (2048,), (2049,), (64, 3, 7, 7), (5000,)]
+    ps = [torch.nn.Parameter(torch.randn(sz, generator=g).cuda()) for sz in sizes]
+    single = [p.detach().clone() for p in ps]
+    ms, vs = [torch.zeros_like(p) for p in single], [torch.zeros_like(p) for p in single]
+    ref = [torch.nn.Parameter(p.detach().clone().cpu()) for p in ps]
+    opt, ropt = HipAdam(ps, lr=1e-3), torch.optim.Adam(ref, lr=1e-3)
+    for step in range(1, 4):
+        grads = [torch.randn(sz, generator=g) for sz in sizes]
+        for p, r, gr, q, m, v in zip(ps, ref, grads, single, ms, vs):
+            p.grad, r.grad = gr.cuda(), gr.clone()
+            K.adam_step(q, gr.cuda(), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
+        opt.step()
+        ropt.step()
+    assert len(opt._multi) == 1
+    for p, q, r in zip(ps, single, ref):
+        assert torch.equal(p.detach(), q)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert opt.state[ps[-1]]["step"] == 3
+
+
 def test_augment_bit_exact(K):
     g = torch.Generator().manual_seed(12)
     imgs = torch.randint(0, 256, (6, 64, 48, 3), dtype=torch.uint8, generator=g)
