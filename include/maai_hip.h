@@ -219,6 +219,22 @@ int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, do
                    double eps, int step, float grad_scale, void* stream);
 int maai_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float weight_decay,
                   int first_step, void* stream);
+/* Kernel-layout copies of the fp32 master convolution weights [Cout][Cin][KH][KW], any number of layers and forms in
+ * one launch.  mode 0 (forward operand): out[co][a][b][ci] = w[co][ci][khs[a]][kws[b]] for ci < Cin, 0 up to cin_pad;
+ * mode 1 (data-gradient operand): out[ci][a][b][co] = w[co][ci][khs[a]][kws[b]].  forms[], block_form[], block_first[]
+ * are device arrays: block b converts 1024 consecutive output elements of forms[block_form[b]] from block_first[b]. */
+typedef struct {
+  const float* w;
+  void* out;
+  int Cout, Cin, KH, KW;
+  int mode;
+  int nkh, nkw, cin_pad;
+  int khs[8], kws[8];
+  int dtype;
+  int reserved;
+} maai_weight_form;
+int maai_weight_forms(const maai_weight_form* forms, const int* block_form, const long long* block_first, int nblocks,
+                      void* stream);
 /* the same Adam update for every tensor of a parameter group in one launch (they share lr / betas / eps / step):
  * slots[] (device memory) lists the tensors; block b of the launch updates 2048 consecutive elements of tensor
  * block_slot[b] starting at element block_first[b] (both device arrays of nblocks entries, built by the host from

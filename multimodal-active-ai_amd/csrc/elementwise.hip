@@ -353,6 +353,47 @@ extern "C" int maai_adam_step(float* p, const float* g, float* m, float* v, long
   return MAAI_OK;
 }
 
+// ---------------------------------------------------------------------------
+// kernel-layout copies of the fp32 master weights (resnet.py:20-28 conv weights [Cout][Cin][KH][KW]), all layers in
+// ONE launch after each optimiser step: forward form [Cout][a][b][Cin_pad] and data-gradient form [Cin][a][b][Cout]
+// over a listed subset of taps (a, b index khs[] / kws[]; the stride-2 gradient's parity classes use subsets, the
+// stride-1 gradient the reversed full list).  Built per layer with torch ops this was ~400 launches per step, each
+// shorter than its issue time.  Block b converts 1024 output elements of form block_form[b] from block_first[b].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void weight_forms_kernel(const maai_weight_form* __restrict__ forms, const int* __restrict__ block_form,
+                                                           const long long* __restrict__ block_first) {
+  const maai_weight_form f = forms[block_form[blockIdx.x]];
+  const long long total = f.mode == 0 ? (long long)f.Cout * f.nkh * f.nkw * f.cin_pad : (long long)f.Cin * f.nkh * f.nkw * f.Cout;
+  const int inner = f.mode == 0 ? f.cin_pad : f.Cout;
+  const int kk = f.KH * f.KW;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = block_first[blockIdx.x] + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    const int in = (int)(i % inner);
+    long long r = i / inner;
+    const int b = (int)(r % f.nkw);
+    r /= f.nkw;
+    const int a = (int)(r % f.nkh);
+    const int outer = (int)(r / f.nkh);
+    const int co = f.mode == 0 ? outer : in, ci = f.mode == 0 ? in : outer;
+    float v = 0.f;
+    if (ci < f.Cin) v = f.w[((long long)co * f.Cin + ci) * kk + f.khs[a] * f.KW + f.kws[b]];
+    if (f.dtype == MAAI_BF16)
+      reinterpret_cast<bf16_t*>(f.out)[i] = f32_to_bf16(v);
+    else
+      reinterpret_cast<float*>(f.out)[i] = v;
+  }
+}
+
+extern "C" int maai_weight_forms(const maai_weight_form* forms, const int* block_form, const long long* block_first, int nblocks,
+                                 void* stream) {
+  MAAI_CHECK_ARG(forms && block_form && block_first && nblocks > 0, "weight_forms: bad arguments");
+  hipLaunchKernelGGL(weight_forms_kernel, dim3(nblocks), dim3(256), 0, ST(stream), forms, block_form, block_first);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 // all parameter tensors of a group in ONE launch: ~160 launches per step otherwise, each shorter than the time
 // the host needs to issue it.  slots[] and the block map live in device memory; block b updates 2048 elements of
 // tensor block_slot[b] starting at block_first[b].

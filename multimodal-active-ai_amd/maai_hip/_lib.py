@@ -36,6 +36,7 @@ _P_EPI = C.POINTER(ConvEpilogue)
 # name -> (restype, argtypes); mirrors include/maai_hip.h line by line
 SIGNATURES = {
     "maai_abi_version": (c_i, []),
+    "maai_weight_forms": (c_i, [c_p, c_p, c_p, c_i, c_p]),
     "maai_adam_step_multi": (c_i, [c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, c_i, C.c_float, c_p]),
     "maai_last_error": (C.c_char_p, []),
     "maai_device_count": (c_i, []),

@@ -14,6 +14,7 @@ Parameters stay ordinary fp32 ``nn.Parameter`` s in the reference layout
 cached per optimiser step.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -75,6 +76,8 @@ def _cached(param, tag, dtype, build):
 
 def clear_weight_cache():
     _CACHE.clear()
+    _FORMS["reg"] = None
+    _FORMS["index"].clear()
 
 
 def _cast(t, dtype):
@@ -82,8 +85,60 @@ def _cast(t, dtype):
     return K.cast_from_f32(t, dtype) if dtype != torch.float32 else t
 
 
+# Kernel-layout copies of the convolution weights go through one registry: a copy requested for the first time is
+# converted on its own; once any copy is found stale (the optimiser stepped), ALL registered copies are refreshed
+# by a single launch (kernels.WeightForms) — ~400 tiny torch kernels per step otherwise.
+_FORMS = {"reg": None, "index": {}}
+
+
+def _form(param, dtype, tag, mode, khs, kws, cin_pad=None):
+    if _FORMS["reg"] is None:
+        _FORMS["reg"] = K.WeightForms()
+    reg = _FORMS["reg"]
+    key = (id(param), tag, dtype)
+    ver = (param._version, _WEIGHT_EPOCH[0], param.data_ptr())
+    hit = _FORMS["index"].get(key)
+    if hit is not None and hit[3]() is not param:
+        hit = None   # the id was recycled by a new parameter object
+    if hit is None:
+        _purge_forms()
+        reg = _FORMS["reg"]
+        with torch.no_grad():
+            idx, out = reg.add(param.detach(), dtype, mode, khs, kws, cin_pad)
+            reg.run([idx])
+        _FORMS["index"][key] = [ver, out, idx, weakref.ref(param)]
+        return out
+    if hit[0] != ver:
+        with torch.no_grad():
+            reg.run()   # everything registered, one launch
+        for h in _FORMS["index"].values():
+            q = h[3]()
+            if q is not None:
+                h[0] = (q._version, _WEIGHT_EPOCH[0], q.data_ptr())
+    return hit[1]
+
+
+def _purge_forms():
+    """Drop the copies of parameters that no longer exist (models come and go in tests and sweeps)."""
+    idx = _FORMS["index"]
+    dead = [k for k, h in idx.items() if h[3]() is None]
+    if not dead:
+        return
+    for k in dead:
+        del idx[k]
+    old = _FORMS["reg"]
+    reg = K.WeightForms()
+    for h in idx.values():
+        reg.entries.append(old.entries[h[2]])
+        h[2] = len(reg.entries) - 1
+    _FORMS["reg"] = reg
+
+
 def w_fwd(param, dtype, cin_pad=None):
     """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin(_pad)]"""
+    if param.is_cuda and param.dim() == 4 and param.is_contiguous() and param.shape[2] <= 8 and param.shape[3] <= 8:
+        return _form(param, dtype, ("fwd", cin_pad), 0, list(range(param.shape[2])), list(range(param.shape[3])), cin_pad)
+
     def build(w):
         w = w.permute(0, 2, 3, 1)
         if cin_pad is not None and cin_pad != w.shape[3]:
@@ -120,6 +175,9 @@ def dgrad_classes(k, stride, pad):
 
 def w_dgrad(param, dtype, khs, kws):
     """[Cout,Cin,KH,KW] -> [Cin,len(khs),len(kws),Cout] taking the listed taps in order."""
+    if param.is_cuda and param.dim() == 4 and param.is_contiguous() and len(khs) <= 8 and len(kws) <= 8:
+        return _form(param, dtype, ("dgrad", tuple(khs), tuple(kws)), 1, list(khs), list(kws))
+
     def build(w):
         w = w[:, :, khs][:, :, :, kws]
         return _cast(w.permute(1, 2, 3, 0), dtype)

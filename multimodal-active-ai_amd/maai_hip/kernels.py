@@ -519,6 +519,73 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
                                int(step), float(grad_scale), _stream()), "maai_adam_step")
 
 
+WEIGHT_FORM_DTYPE = [("w", "<u8"), ("out", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"), ("KH", "<i4"), ("KW", "<i4"), ("mode", "<i4"),
+                     ("nkh", "<i4"), ("nkw", "<i4"), ("cin_pad", "<i4"), ("khs", "<i4", (8,)), ("kws", "<i4", (8,)), ("dtype", "<i4"),
+                     ("reserved", "<i4")]   # maai_weight_form, 120 bytes
+
+
+class WeightForms(object):
+    """Registry of kernel-layout weight copies refreshed by ONE launch (maai_weight_forms).  ``add`` registers a
+    form and returns its output tensor; ``run`` converts the listed forms (all by default)."""
+    CHUNK = 1024
+
+    def __init__(self):
+        self.entries = []      # (param, out, mode, khs, kws, cin_pad)
+        self._tables = None    # (forms_dev, block_form_dev, block_first_dev, nblocks, ptrs) for the whole registry
+
+    def add(self, param, dtype, mode, khs, kws, cin_pad=None):
+        import numpy as np
+        if param.dim() != 4 or param.dtype != torch.float32 or not param.is_contiguous():
+            raise MaaiError("weight form: expected a contiguous fp32 [Cout,Cin,KH,KW] parameter")
+        if len(khs) > 8 or len(kws) > 8 or not khs or not kws:
+            raise MaaiError("weight form: 1..8 taps per axis")
+        _gpu(param)
+        co, ci = param.shape[0], param.shape[1]
+        cp = ci if cin_pad is None else cin_pad
+        shape = (co, len(khs), len(kws), cp) if mode == 0 else (ci, len(khs), len(kws), co)
+        out = torch.empty(shape, dtype=dtype, device=param.device)
+        self.entries.append((param, out, mode, tuple(khs), tuple(kws), cp))
+        self._tables = None
+        return len(self.entries) - 1, out
+
+    def _build(self, idxs):
+        import numpy as np
+        forms = np.zeros(len(idxs), dtype=np.dtype(WEIGHT_FORM_DTYPE))
+        slot, first = [], []
+        for j, i in enumerate(idxs):
+            param, out, mode, khs, kws, cp = self.entries[i]
+            f = forms[j]
+            f["w"], f["out"] = param.data_ptr(), out.data_ptr()
+            f["Cout"], f["Cin"], f["KH"], f["KW"] = param.shape
+            f["mode"], f["nkh"], f["nkw"], f["cin_pad"] = mode, len(khs), len(kws), cp
+            f["khs"][:len(khs)] = khs
+            f["kws"][:len(kws)] = kws
+            f["dtype"] = BF16 if out.dtype == torch.bfloat16 else F32
+            nb = (out.numel() + self.CHUNK - 1) // self.CHUNK
+            slot.append(np.full(nb, j, dtype=np.int32))
+            first.append(np.arange(nb, dtype=np.int64) * self.CHUNK)
+        dev = self.entries[idxs[0]][0].device
+        fd = torch.from_numpy(forms.view(np.uint8).reshape(-1)).to(dev)
+        bs = torch.from_numpy(np.concatenate(slot)).to(dev)
+        bf = torch.from_numpy(np.concatenate(first)).to(dev)
+        return fd, bs, bf, int(bs.numel()), tuple(self.entries[i][0].data_ptr() for i in idxs)
+
+    def run(self, idxs=None):
+        if not self.entries:
+            return
+        if idxs is None:
+            ptrs = tuple(e[0].data_ptr() for e in self.entries)
+            if self._tables is None or self._tables[4] != ptrs:
+                self._tables = self._build(list(range(len(self.entries))))
+            t = self._tables
+        else:
+            t = self._build(list(idxs))
+        check(lib().maai_weight_forms(_p(t[0]), _p(t[1]), _p(t[2]), t[3], _stream()), "maai_weight_forms")
+        if idxs is not None:
+            # the temporary tables must outlive the launch; the caching allocator keeps them stream-ordered
+            t[0].record_stream(torch.cuda.current_stream())
+
+
 class AdamMulti(object):
     """One-launch Adam over a fixed list of fp32 tensors (maai_adam_step_multi).  The block map depends on the sizes
     only and is built once; the slot table is re-uploaded per step because gradient tensors are new every step."""

@@ -680,3 +680,43 @@ def test_foveated_retinal_processor_matches_oracle(K):
     for v, r in zip(v2, r2):
         assert np.abs(v.cpu().numpy().astype(np.int32) - r.astype(np.int32)).max() <= 1
     assert not np.array_equal(views[3].cpu().numpy(), v2[3].cpu().numpy())
+
+
+def test_batched_weight_forms_match_the_torch_construction(K):
+    """engine.w_fwd / w_dgrad on device parameters go through ONE-launch conversion (maai_weight_forms): same bits
+    as permute + index + cast, for full and subset tap lists, channel padding, fp32 and bf16; the whole registry is
+    refreshed (in place) when any parameter changes."""
+    from maai_hip import engine
+    engine.clear_weight_cache()
+    g = torch.Generator().manual_seed(4)
+    w3 = torch.nn.Parameter(torch.randn(128, 64, 3, 3, generator=g).cuda())
+    w1 = torch.nn.Parameter(torch.randn(256, 64, 1, 1, generator=g).cuda())
+    w12 = torch.nn.Parameter(torch.randn(64, 12, 7, 7, generator=g).cuda())
+
+    def ref_fwd(w, dtype, pad=None):
+        t = w.detach().permute(0, 2, 3, 1)
+        if pad:
+            t = torch.nn.functional.pad(t, (0, pad - t.shape[3]))
+        return t.contiguous().to(dtype)
+
+    def ref_dgrad(w, dtype, khs, kws):
+        return w.detach()[:, :, khs][:, :, :, kws].permute(1, 2, 3, 0).contiguous().to(dtype)
+    for dtype in (torch.bfloat16, torch.float32):
+        assert torch.equal(engine.w_fwd(w3, dtype), ref_fwd(w3, dtype))
+        assert torch.equal(engine.w_fwd(w1, dtype), ref_fwd(w1, dtype))
+        assert torch.equal(engine.w_fwd(w12, dtype, 32), ref_fwd(w12, dtype, 32))
+        assert torch.equal(engine.w_dgrad(w3, dtype, [2, 1, 0], [2, 1, 0]), ref_dgrad(w3, dtype, [2, 1, 0], [2, 1, 0]))
+        assert torch.equal(engine.w_dgrad(w3, dtype, [1], [2, 0]), ref_dgrad(w3, dtype, [1], [2, 0]))
+        assert torch.equal(engine.w_dgrad(w1, dtype, [0], [0]), ref_dgrad(w1, dtype, [0], [0]))
+    a = engine.w_fwd(w3, torch.bfloat16)
+    b = engine.w_dgrad(w1, torch.bfloat16, [0], [0])
+    with torch.no_grad():
+        w3.mul_(2.0)
+        w1.add_(1.0)
+    assert engine.w_fwd(w3, torch.bfloat16) is a and torch.equal(a, ref_fwd(w3, torch.bfloat16))
+    assert torch.equal(b, ref_dgrad(w1, torch.bfloat16, [0], [0]))   # refreshed by the same launch
+    del w12
+    w5 = torch.nn.Parameter(torch.randn(64, 32, 3, 3, generator=g).cuda())
+    assert torch.equal(engine.w_fwd(w5, torch.bfloat16), ref_fwd(w5, torch.bfloat16))   # registration purges dead entries
+    assert len(engine._FORMS["reg"].entries) == len(engine._FORMS["index"])
+    engine.clear_weight_cache()

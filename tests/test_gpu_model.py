@@ -397,12 +397,26 @@ def test_block_recompute_matches_stored_activations(mods, prec):
         try:
             m = _build(mods, "resnet50", 1, 2048 * 16, 4, (32, 32), 0.5)
             m.train()
-            torch.cuda.synchronize()
-            base = torch.cuda.memory_allocated()
             with torch.no_grad():
                 feat, tape = engine.backbone_fwd(m.f, x, dtype, keep=True)
             torch.cuda.synchronize()
-            held = torch.cuda.memory_allocated() - base
+            seen = {}
+
+            def note(t):
+                if torch.is_tensor(t):
+                    seen[t.untyped_storage().data_ptr()] = t.untyped_storage().nbytes()
+
+            def walk(o):
+                if isinstance(o, (tuple, list)):
+                    for q in o:
+                        walk(q)
+                elif isinstance(o, engine._Rec):
+                    for f in ("x", "y", "out", "bits"):
+                        note(getattr(o, f, None))
+                else:
+                    note(o)
+            walk(tape)
+            held = sum(seen.values())   # bytes the tape keeps alive between forward and backward
             g = torch.Generator().manual_seed(9)
             dout = torch.randn(feat.shape, generator=g).to(dtype).cuda()
             grads = {}
