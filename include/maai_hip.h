@@ -97,9 +97,21 @@ typedef struct {
   const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y;
                         DGRAD_REDUCE: the lower layer's raw conv output, laid out like y */
   int mask_bits;     /* DGRAD_REDUCE, bf16: relu_mask is the 1-bit mask of maai_bn_act_fwd_mask, not a tensor */
+  int reserved;
+  /* DGRAD_REDUCE on a pointwise bf16 layer, optional: the A operand of the GEMM is not x itself but
+   * k1[c]*x - k2[c] - k3[c]*a2 per input channel c, i.e. the BatchNorm-backward apply of the layer whose gradient
+   * this convolution propagates (x = dz, a2 = that layer's raw conv output), formed while staging instead of by a
+   * maai_bn_act_bwd_apply pass that writes it and this launch reading it back.  a_out (nullable) receives the
+   * transformed operand [M][Cin] for the weight gradient.  NULL a2 = plain operand. */
+  const void* a2;
+  const float* ak1;
+  const float* ak2;
+  const float* ak3;
+  void* a_out;
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);
+long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):
  *   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]

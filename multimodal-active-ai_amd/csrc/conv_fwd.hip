@@ -73,6 +73,13 @@ struct ConvArgs {
   const void* et;
   int mask_bits;  // mask is a 1-bit-per-element array (maai_bn_act_fwd_mask), EMODE 6 / 16-bit types only
   int tilesX, tilesY;  // HALO kernels: 16-wide x BM/16-high output patches per image
+  // AXF kernels: the A operand is k1*x - k2 - k3*a2 per input channel (BatchNorm-backward apply of the layer above),
+  // computed while staging; a_out (nullable) receives it for the weight gradient
+  const void* a2;
+  const float* ak1;
+  const float* ak2;
+  const float* ak3;
+  void* a_out;
 };
 
 // EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
@@ -82,7 +89,11 @@ struct ConvArgs {
 // and the A operand is its (BM/16+2) x 18 input halo, staged once per 32-channel chunk and read by all nine taps
 // at shifted pixel addresses, instead of nine separately staged 64-byte row sets: 2.3-3.4x fewer LDS-DMA bytes per
 // MFMA on the layers whose K loop is bound by exactly that traffic.  K order: chunk-major, tap-minor.
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false>
+// AXF (pointwise data gradients): A = k1*dz - k2 - k3*y — the BatchNorm-backward apply of the layer whose gradient
+// this convolution propagates — is computed on the way into LDS (global -> registers -> LDS, two slots) instead of
+// being written by a separate pass and read back; the transformed operand is also stored once (column tile 0) for
+// the weight gradient.  Same arithmetic, same bits as maai_bn_act_bwd_apply followed by the plain kernel.
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
 __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
@@ -229,6 +240,89 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
     hoff[q] = px * 64 + (((lane >> 4) ^ (((px >> 2) & 1) << 1)) << 4);
   }
   int ctap = 0, cchunk = 0;
+  if constexpr (AXF) {
+    static_assert(!AXF || (PW && !HALO && sizeof(T) == 2 && BM == 128), "AXF: pointwise bf16 128-row tiles");
+    constexpr int SLOT = (BM + BN) * 64;
+    float* coef = reinterpret_cast<float*>(smem + 2 * SLOT);  // k1 | k2 | k3, K floats each
+    for (int i = tid; i < 3 * K; i += 256) coef[i] = i < K ? a.ak1[i] : (i < 2 * K ? a.ak2[i - K] : a.ak3[i - 2 * K]);
+    const T* __restrict__ y2 = reinterpret_cast<const T*>(a.a2);
+    T* __restrict__ dyo = reinterpret_cast<T*>(a.a_out);
+    const bool keep_dy = dyo != nullptr && nb == 0;
+    Vec16<T> rz[AR], ry[AR];
+    auto load_a = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < AR; ++i)
+        if (ihb[i] >= 0) {
+          rz[i].load(x + abase[i] + (long long)kt * BK);
+          ry[i].load(y2 + abase[i] + (long long)kt * BK);
+        }
+    };
+    auto issue_b = [&](int kt, int slot) {
+      char* sb = smem + slot * SLOT + BM * 64 + widu * 1024;
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + (long long)kt * BK),
+                                         (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
+    };
+    auto store_a = [&](int kt, int slot) {
+      const float* c1 = coef + kt * BK + chunk * EPC;
+      float q1[8], q2[8], q3[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        q1[e] = c1[e];
+        q2[e] = c1[K + e];
+        q3[e] = c1[2 * K + e];
+      }
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        float d[8], yy[8];
+        Vec16<T> v;
+        if (ihb[i] >= 0) {
+          rz[i].get(d);
+          ry[i].get(yy);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = q1[e] * d[e] - q2[e] - q3[e] * yy[e];
+          v.set(d);
+          if (keep_dy) v.store(dyo + abase[i] + (long long)kt * BK);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = 0.f;
+          v.set(d);
+        }
+        v.store(reinterpret_cast<T*>(smem + slot * SLOT + (r0 + 64 * i) * 64 + (tid & 3) * 16));
+      }
+    };
+    load_a(0);
+    issue_b(0, 0);
+    __syncthreads();  // coefficients are in LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_a(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int slot = kt & 1;
+      if (kt + 1 < KT) {  // slot^1 was last read in iteration kt-1, whose closing barrier everyone has passed
+        load_a(kt + 1);
+        issue_b(kt + 1, slot ^ 1);
+      }
+      const char* sa = smem + slot * SLOT + (wm * WM) * 64 + foff;
+      const char* sb = smem + slot * SLOT + BM * 64 + (wn * WN) * 64 + foff;
+      frag_t af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * 16 * 64);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+      if (kt + 1 < KT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_a(kt + 1, slot ^ 1);
+      }
+      __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
   const int pre = KT < NSTAGE - 1 ? KT : NSTAGE - 1;
   for (int s = 0; s < pre; ++s) issue_stage(s, s);
 
@@ -267,6 +361,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+  }
   }
   __syncthreads();  // all DMA retired (vmcnt(0) above); the ring is now reused as the C tile
   if constexpr (HALO) {
@@ -576,20 +671,22 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void con
   }
 }
 
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false>
+template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
 static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int stage = HALO ? NSTAGE * BN * 64 + 2 * (((BM / 16 + 2) * 24 + 63) / 64) * 4096 : NSTAGE * (BM + BN) * 64;
   constexpr int epi = (BM < 128 ? BM : 128) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
-  constexpr int lds = stage > epi ? stage : epi;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO>),
+  const int axf_lds = AXF ? 2 * (BM + BN) * 64 + 12 * a.KH * a.KW * a.Cin : 0;  // two slots + k1|k2|k3
+  const int lds0 = stage > epi ? stage : epi;
+  const int lds = AXF ? (axf_lds > epi ? axf_lds : epi) : lds0;
+  static int attr_lds = -1;
+  if (lds > attr_lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
+    attr_lds = lds;
   }
   const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -756,6 +853,17 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.ep2 = epi ? epi->p2 : nullptr;
   a.et = epi ? epi->t : nullptr;
   a.mask_bits = epi ? epi->mask_bits : 0;
+  a.a2 = epi ? epi->a2 : nullptr;
+  a.ak1 = epi ? epi->ak1 : nullptr;
+  a.ak2 = epi ? epi->ak2 : nullptr;
+  a.ak3 = epi ? epi->ak3 : nullptr;
+  a.a_out = epi ? epi->a_out : nullptr;
+  const bool axf = a.a2 != nullptr;
+  if (axf) {
+    const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+    MAAI_CHECK_ARG(emode == MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && pw1 && a.ak1 && a.ak2 && a.ak3 && d->Cin <= 4096,
+                   "conv2d_igemm: the transformed A operand is for bf16 pointwise DGRAD_REDUCE launches with k1, k2, k3");
+  }
   MAAI_CHECK_ARG(!a.mask_bits || (emode == MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && relu_mask),
                  "conv2d_igemm: the 1-bit mask is for the bf16 DGRAD_REDUCE epilogue");
   a.M = (long long)d->N * d->OHg * d->OWg;
@@ -775,7 +883,12 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
     return maai_pw_conv_launch(p, emode, st);
   }
-  const ConvPlan plan = conv_plan(d, dtype);
+  ConvPlan plan = conv_plan(d, dtype);
+  if (axf) {  // 128-row tiles only (register-staged operand)
+    plan.bm = 128;
+    plan.halo = false;
+    plan.nMB = (a.M + 127) / 128;
+  }
   const int bm = plan.bm;
   a.nMB = (int)plan.nMB;
   a.tilesX = plan.tilesX;
@@ -784,6 +897,9 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
   const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);
+  if (axf) {
+    return n128 ? launch_conv_p<bf16_t, 128, 128, 2, 6, true, false, true>(a, st) : launch_conv_p<bf16_t, 128, 64, 2, 6, true, false, true>(a, st);
+  }
   if (dtype == MAAI_BF16) {
     if (bm == 64) return n128 ? launch_conv<bf16_t, 64, 128>(a, st) : launch_conv<bf16_t, 64, 64>(a, st);
     if (bm == 256) return n128 ? launch_conv_n<bf16_t, 256, 128, 3>(a, st) : launch_conv_n<bf16_t, 256, 64, 3>(a, st);
@@ -794,6 +910,13 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
 }
 
 /* rows of the statistics slab: one per M-tile of the kernel maai_conv2d_igemm picks for (d, dtype) */
+/* the same for a launch with an epilogue descriptor (the transformed-operand launches use 128-row tiles) */
+extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype) {
+  if (!d) return 0;
+  if (epi && epi->a2) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  return conv_plan(d, dtype).nMB;
+}
+
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {
   if (!d) return 0;
   return conv_plan(d, dtype).nMB;

@@ -352,11 +352,31 @@ def _reduce_mean(rec):
     return rec.mean if rec.training else rec.bn.running_mean
 
 
-def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None):
+# MAAI_AXF: 0 never, 1 where measured to pay (default), 2 wherever possible.  Measured in bench.py (B = 256, per launch,
+# apply pass + data gradient): layer-1 conv3 (K = 256 -> 64 columns) 5.74 -> 4.47 ms; every other pointwise layer loses
+# (layer-2 conv3 2.02 -> 2.47, layer-3 conv3 0.92 -> 1.73, the expanding conv1 gradients 4.93 -> 5.23 ms): the
+# register-staged operand path waits out each stage's loads and, with several column tiles, reads dz and y per tile.
+_AXF = {"mode": int(os.environ.get("MAAI_AXF", "1"))}
+
+
+def axf_applies(rec, dz, below, need_dx=True):
+    """Should the BatchNorm-backward apply of ``rec`` be formed inside its own data-gradient launch?  (pointwise bf16
+    unit whose data gradient also reduces the sums of the unit below)"""
+    ok = (_AXF["mode"] > 0 and need_dx and not rec.fused and rec.y is not None and rec.k == 1 and rec.stride == 1 and rec.pad == 0
+          and dz.dtype == torch.bfloat16 and below is not None and _DGRAD_REDUCE["enabled"] and below.y is not None
+          and rec.conv.weight.shape[0] <= 4096)
+    if ok and _AXF["mode"] == 1:
+        ok = rec.conv.weight.shape[0] <= 256 and rec.conv.weight.shape[1] <= 64
+    return ok
+
+
+def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None, axf=None):
     """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]; with ``relu_mask`` (= x,
     a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue.  ``below`` = the record of
     the unit whose output x is: the mask is then that unit's, and where every pixel of dx is written exactly once
-    the unit's BN-backward sums are reduced in the same epilogue.  Returns (dx, fp64 sums [2C] or None)."""
+    the unit's BN-backward sums are reduced in the same epilogue.  Returns (dx, fp64 sums [2C] or None).
+    ``axf = (y, k1, k2, k3, dy_out)``: ``dy`` is really dz and the operand k1*dz - k2 - k3*y is formed in the launch
+    (pointwise layers with ``below``; see kernels.conv2d_store_reduce)."""
     n, cin = dy.shape[0], weight.shape[1]
     ih, iw = in_hw
     cls = dgrad_classes(k, stride, pad)
@@ -385,19 +405,22 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
             if gh <= 0 or gw <= 0:
                 continue
             launches.append((w_dgrad(weight, dtype, khs, kws), pad_h, pad_w, (gh, gw), (a, b)))
+    if axf is not None and not (fuse and len(launches) == 1):
+        raise MaaiError("conv_dgrad: the transformed operand needs a single fused pointwise launch")
     if not fuse:
         for (wq, pad_h, pad_w, grid, off) in launches:
             K.conv2d(dy, wq, 1, pad_h, pad_w, out=out, grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off,
                      accumulate=accumulate, relu_mask=relu_mask)
         return out, None
-    rows = [K.conv2d_stats_rows(dy, wq, 1, pad_h, pad_w, grid, (ih, iw), stride, off) for (wq, pad_h, pad_w, grid, off) in launches]
+    rows = [K.conv2d_stats_rows(dy, wq, 1, pad_h, pad_w, grid, (ih, iw), stride, off, axf=axf is not None)
+            for (wq, pad_h, pad_w, grid, off) in launches]
     slab = torch.empty((sum(rows), 2, cin), dtype=torch.float32, device=dy.device)
     r0 = 0
     for (wq, pad_h, pad_w, grid, off), nr in zip(launches, rows):
         K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], below.y, _reduce_mean(below),
                               below.scale if from_y else None, below.shift if from_y else None, relu_mask,
                               grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate,
-                              mask_bits=use_bits)
+                              mask_bits=use_bits, axf=axf)
         r0 += nr
     return out, K.reduce_partials(slab)
 
@@ -459,7 +482,17 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
     from the same epilogue).  ``presums`` = this unit's own sums if the producer of ``dout`` already reduced them;
     ``dy`` = the gradient wrt the raw conv output if the caller already ran the BatchNorm backward.
     Returns (dx or None, sums for ``below`` or None); parameter gradients go to ``grads``."""
-    if dy is None:
+    fused_apply = dy is None and axf_applies(rec, dout, below, need_dx) and not any(
+        len(c[1]) == 0 for c in dgrad_classes(rec.k, rec.stride, rec.pad))
+    if fused_apply:
+        # the apply pass (dy = k1*dz - k2 - k3*y) happens inside the data-gradient launch, which also hands dy back
+        # for the weight gradient: dz and y are read once, dy is written once and read once
+        k1, k2, k3 = unit_bwd_coeffs(rec, dout, grads, dtype, presums)
+        dy = torch.empty_like(dout) if rec.conv.weight.requires_grad else None
+        dx, below_sums = conv_dgrad(dout, rec.conv.weight, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out,
+                                    accumulate=accumulate, relu_mask=relu_mask, below=below, axf=(rec.y, k1, k2, k3, dy))
+        need_dx = False
+    elif dy is None:
         k1, k2, k3 = unit_bwd_coeffs(rec, dout, grads, dtype, presums)
         if rec.fused:
             dy = K.conv2d_bwd_apply(rec.x, w_fwd(rec.conv.weight, dtype), dout, k1, k2, k3)
@@ -482,7 +515,8 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         else:
             dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
             grads[id(w)] = _grad_to_reference(rec, dw)
-    dx, below_sums = None, None
+    if not fused_apply:
+        dx, below_sums = None, None
     if need_dx:
         dx, below_sums = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate,
                                     relu_mask=relu_mask, below=below)

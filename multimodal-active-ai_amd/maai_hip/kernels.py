@@ -135,17 +135,21 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     return (out, part) if stats else out
 
 
-def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0)):
-    """Rows of the partial-sum slab one conv2d launch of this geometry writes."""
+def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), axf=False):
+    """Rows of the partial-sum slab one conv2d launch of this geometry writes (``axf``: transformed-operand launch)."""
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, False)
+    if axf:
+        return (d.N * d.OHg * d.OWg + 127) // 128
     return int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
 
 
 def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
-                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False):
+                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False, axf=None):
     """conv2d(..., out=out) for a data gradient whose epilogue also reduces the BatchNorm-backward partial sums of
     the stored values g: rows of ``part`` [rows,2,Cout] get sum(g) and sum(g*(lower_y - mean)).  The ReLU mask is
-    ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE)."""
+    ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE).
+    ``axf = (y_raw, k1, k2, k3, dy_out)``: x is dz and the GEMM operand is k1*dz - k2 - k3*y_raw (BatchNorm-backward
+    apply of the layer above), formed while staging; dy_out (or None) receives it.  Pointwise bf16 layers only."""
     _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask)
     if x.dtype != w.dtype or lower_y.dtype != out.dtype or lower_y.shape != out.shape:
         raise MaaiError("conv2d_store_reduce: operand dtype / shape mismatch")
@@ -155,16 +159,24 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     elif relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
         raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
-    rows = int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
+    epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
+                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0, 0)
+    if axf is not None:
+        ya, k1, k2, k3, dyo = axf
+        _gpu(ya, k1, k2, k3, dyo)
+        if ya.shape != x.shape or ya.dtype != x.dtype or (dyo is not None and (dyo.shape != x.shape or dyo.dtype != x.dtype)):
+            raise MaaiError("conv2d_store_reduce: the transformed operand's tensors must match x")
+        epi.a2, epi.ak1, epi.ak2, epi.ak3 = ya.data_ptr(), k1.data_ptr(), k2.data_ptr(), k3.data_ptr()
+        epi.a_out = None if dyo is None else dyo.data_ptr()
+    rows = int(lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(x)))
     if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != (rows, 2, d.Cout):
         raise MaaiError("conv2d_store_reduce: partial slab must be fp32 [%d, 2, %d]" % (rows, d.Cout))
-    epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
-                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0)
     m = d.N * d.OHg * d.OWg
     es = x.element_size()
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[red] M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
-                es * (x.numel() + w.numel() + m * d.Cout * (2 + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
+                es * (x.numel() * (1 if axf is None else (3 if axf[4] is not None else 2)) + w.numel()
+                      + m * d.Cout * (2 + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
                 + (m * d.Cout // 8 if mask_bits else 0)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")

@@ -720,3 +720,42 @@ def test_batched_weight_forms_match_the_torch_construction(K):
     assert torch.equal(engine.w_fwd(w5, torch.bfloat16), ref_fwd(w5, torch.bfloat16))   # registration purges dead entries
     assert len(engine._FORMS["reg"].entries) == len(engine._FORMS["index"])
     engine.clear_weight_cache()
+
+
+@pytest.mark.parametrize("case", [(2, 256, 9, 9, 64, False), (3, 64, 7, 5, 256, True), (1, 512, 12, 12, 128, False), (2, 128, 30, 30, 192, True)])
+def test_conv_transformed_operand_matches_apply_then_conv(K, case):
+    """DGRAD_REDUCE with the BatchNorm-backward apply formed while staging the A operand (k1*dz - k2 - k3*y):
+    the stored gradient, the handed-back operand dy and the sums against the two-launch sequence
+    maai_bn_act_bwd_apply -> plain DGRAD_REDUCE launch.  Same arithmetic, so dx and dy must be bit-identical."""
+    n, cin, h, w, cout, acc = case
+    g = torch.Generator().manual_seed(91 + cin)
+    dt = torch.bfloat16
+    dz = nhwc(torch.randn(n, cin, h, w, generator=g), dt)
+    yup = nhwc(torch.randn(n, cin, h, w, generator=g), dt)
+    k1, k2, k3 = (torch.randn(cin, generator=g).cuda() for _ in range(3))
+    wq = khwc(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    ylow = nhwc(torch.randn(n, cout, h, w, generator=g), dt)
+    base = nhwc(torch.randn(n, cout, h, w, generator=g), dt)
+    mean, scale, shift = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+    # reference: apply pass, then the plain fused launch
+    dy_ref, _ = K.bn_act_bwd_apply(dz, None, yup, k1, k2, k3, False, True, False)
+    want = base.clone() if acc else torch.empty_like(base)
+    rows = K.conv2d_stats_rows(dy_ref, wq, 1, 0, 0, (h, w), (h, w))
+    part_ref = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    K.conv2d_store_reduce(dy_ref, wq, 1, 0, 0, want, part_ref, ylow, mean, scale, shift, None, grid_hw=(h, w), out_hw=(h, w), accumulate=acc)
+    # fused
+    got = base.clone() if acc else torch.empty_like(base)
+    dy = torch.full_like(dz, float("nan"))
+    rows2 = K.conv2d_stats_rows(dz, wq, 1, 0, 0, (h, w), (h, w), axf=True)
+    part = torch.full((rows2, 2, cout), float("nan"), dtype=torch.float32, device="cuda")
+    K.conv2d_store_reduce(dz, wq, 1, 0, 0, got, part, ylow, mean, scale, shift, None, grid_hw=(h, w), out_hw=(h, w), accumulate=acc,
+                          axf=(yup, k1, k2, k3, dy))
+    torch.cuda.synchronize()
+    assert torch.equal(dy, dy_ref)
+    assert torch.equal(got, want)
+    np.testing.assert_allclose(K.reduce_partials(part).cpu().numpy(), K.reduce_partials(part_ref).cpu().numpy(), rtol=2e-5, atol=2e-4)
+    # without the side output
+    got2 = base.clone() if acc else torch.empty_like(base)
+    K.conv2d_store_reduce(dz, wq, 1, 0, 0, got2, part, ylow, mean, scale, shift, None, grid_hw=(h, w), out_hw=(h, w), accumulate=acc,
+                          axf=(yup, k1, k2, k3, None))
+    assert torch.equal(got2, want)

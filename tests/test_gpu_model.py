@@ -345,7 +345,8 @@ def test_linear_probe_flow_on_frozen_backbone(mods, tmp_path):
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_backward_fusions_are_bit_identical(mods, prec):
     """The traffic-saving paths — BN-backward sums reduced in the producing dgrad epilogue, ReLU masks from
-    y*scale+shift / 1-bit masks, and the two-branch BatchNorm pass of downsample blocks — against the plain
+    y*scale+shift / 1-bit masks, the BN-backward apply formed inside the pointwise data gradients, and the two-branch
+    BatchNorm pass of downsample blocks — against the plain
     sequence of passes they replace: same feature map bit for bit, same gradients up to the fp32 summation
     order of the BN sums."""
     from maai_hip import engine
@@ -356,6 +357,7 @@ def test_backward_fusions_are_bit_identical(mods, prec):
     res = {}
     for tag, flags in (("fused", (True, True, True)), ("plain", (False, False, False))):
         engine._DGRAD_REDUCE["enabled"], engine._DGRAD_REDUCE["bits"], engine._DUAL_BN["enabled"] = flags
+        engine._AXF["mode"] = 2 if flags[0] else 0   # BN-backward apply inside every pointwise data gradient / nowhere
         try:
             m = _build(mods, "resnet50", 1, head_in, 4, (32, 32), 0.5)
             m.train()
@@ -370,6 +372,7 @@ def test_backward_fusions_are_bit_identical(mods, prec):
             res[tag] = (feat.float().cpu(), named)
         finally:
             engine._DGRAD_REDUCE["enabled"], engine._DGRAD_REDUCE["bits"], engine._DUAL_BN["enabled"] = True, True, True
+            engine._AXF["mode"] = 1
     assert torch.equal(res["fused"][0], res["plain"][0])
     assert res["fused"][1].keys() == res["plain"][1].keys() and len(res["plain"][1]) > 100
     for n, gp in res["plain"][1].items():
