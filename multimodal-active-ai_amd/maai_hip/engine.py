@@ -367,6 +367,8 @@ def axf_applies(rec, dz, below, need_dx=True):
           and rec.conv.weight.shape[0] <= 4096)
     if ok and _AXF["mode"] == 1:
         ok = rec.conv.weight.shape[0] <= 256 and rec.conv.weight.shape[1] <= 64
+    if ok and _AXF["mode"] == 3:   # experiment: every channel-reducing gradient with a single column tile
+        ok = rec.conv.weight.shape[1] <= 128 and rec.conv.weight.shape[0] >= 4 * rec.conv.weight.shape[1]
     return ok
 
 
