@@ -94,7 +94,7 @@ struct ConvArgs {
 // being written by a separate pass and read back; the transformed operand is also stored once (column tile 0) for
 // the weight gradient.  Same arithmetic, same bits as maai_bn_act_bwd_apply followed by the plain kernel.
 template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
-__global__ __launch_bounds__(256, BM == 256 ? 2 : (EMODE == 6 ? 3 : 1)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
   constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
