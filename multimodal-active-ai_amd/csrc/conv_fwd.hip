@@ -426,11 +426,15 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(Conv
           const f32x4 v = acc[i][j];
           const uint32_t p01 = pack_bf16x2(v[0], v[1]);
           const uint32_t p23 = pack_bf16x2(v[2], v[3]);
-          unsigned short* c = cbase + i * 16 * LDC + j * 16;
-          c[0] = (unsigned short)p01;
-          c[LDC] = (unsigned short)(p01 >> 16);
-          c[2 * LDC] = (unsigned short)p23;
-          c[3 * LDC] = (unsigned short)(p23 >> 16);
+          // one v_cvt_pk per row PAIR: the low half goes out with ds_write_b16, the high half with its d16_hi form
+          // (left to the compiler this became one conversion per value)
+          const uint32_t ca = (uint32_t)(uintptr_t)cbase;   // one base register; the tile position is an immediate offset
+          asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(ca), "v"(p01),
+                       "n"((i * 16 * LDC + j * 16) * 2), "n"((i * 16 * LDC + j * 16) * 2 + LDC * 2)
+                       : "memory");
+          asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(ca), "v"(p23),
+                       "n"((i * 16 * LDC + j * 16) * 2 + LDC * 4), "n"((i * 16 * LDC + j * 16) * 2 + LDC * 6)
+                       : "memory");
         }
     }
   } else {
@@ -453,17 +457,19 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(Conv
     float* sred = red + ((wm * 4 + (lane >> 4)) * 2) * BN + wn * WN + (lane & 15);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s = 0.f, q = 0.f;
+      // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two rows per instruction, half the vector-issue slots
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = acc[i][j][r];
-          s += v;
-          q = __builtin_fmaf(v, v, q);
-        }
-      sred[j * 16] = s;
-      sred[BN + j * 16] = q;
+      for (int i = 0; i < TM; ++i) {
+        const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
+        s2 += lo;
+        q2 = __builtin_elementwise_fma(lo, lo, q2);
+        s2 += hi;
+        q2 = __builtin_elementwise_fma(hi, hi, q2);
+      }
+      sred[j * 16] = s2.x + s2.y;
+      sred[BN + j * 16] = q2.x + q2.y;
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
