@@ -25,6 +25,7 @@
 #include "common.h"
 #include "maai_internal.h"
 #include "conv_pw.h"
+#include "conv_pp.h"
 #include <stdlib.h>
 
 template <typename T> struct Mma;
@@ -888,6 +889,24 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     p.x = x; p.w = w; p.y = y; p.stats = stats_partial; p.mask = relu_mask; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
     p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
     return maai_pw_conv_launch(p, emode, st);
+  }
+  // Forward pointwise layers with a K loop of 4+ steps CAN go to the persistent, software-pipelined kernel (conv_pp.hip:
+  // two resident workgroups per CU walk the tiles, the LDS-DMA ring runs across tile boundaries).  Bit-identical, but
+  // measured slower on MI355X (scripts/conv_pw_ab.py, B = 256: 256->1024 0.78 -> 0.95 ms, 512->2048 0.58 -> 0.75 ms):
+  // whatever holds these layers at 23 % of the matrix pipe, it is not the per-tile latency chain.  Opt-in:
+  // MAAI_PW_PERSIST=1 (read per call).
+  {
+    const char* e = getenv("MAAI_PW_PERSIST");
+    const int forced = e ? atoi(e) : 0;
+    const long long tiles = ((a.M + 127) / 128) * (d->Cout / 128);
+    if (pw && !axf && forced == 1 && dtype == MAAI_BF16 && emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && stats_partial &&
+        d->Cout % 128 == 0 && d->Cin % 32 == 0 && d->Cin / 32 >= 4 && choose_bm(d, dtype) == 128 && tiles < (1ll << 31)) {
+      PpArgs p;
+      p.x = reinterpret_cast<const bf16_t*>(x); p.w = reinterpret_cast<const bf16_t*>(w); p.y = reinterpret_cast<bf16_t*>(y);
+      p.stats = stats_partial; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
+      p.nMB = (int)((a.M + 127) / 128); p.nNB = d->Cout / 128; p.ntiles = (int)tiles;
+      return maai_pp_conv_launch(p, st);
+    }
   }
   ConvPlan plan = conv_plan(d, dtype);
   if (axf) {  // 128-row tiles only (register-staged operand)
