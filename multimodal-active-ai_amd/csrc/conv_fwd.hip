@@ -95,7 +95,7 @@ struct ConvArgs {
 // being written by a separate pass and read back; the transformed operand is also stored once (column tile 0) for
 // the weight gradient.  Same arithmetic, same bits as maai_bn_act_bwd_apply followed by the plain kernel.
 template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
-__global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 4 * EPC;               // 64-byte rows
   constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(Conv
 
   // ---- epilogue ----
   T* ct = reinterpret_cast<T*>(smem);
-  constexpr int CROWS = 128;                // the C tile holds 128 rows; 256-row tiles drain in two phases
+  constexpr int CROWS = BN > 128 ? 64 : 128;  // rows the C tile holds; taller (or 256-column) tiles drain in phases
   constexpr int NPH = BM / CROWS > 0 ? (BM + CROWS - 1) / CROWS : 1;
   float* red = reinterpret_cast<float*>(smem + (BM < CROWS ? BM : CROWS) * LDC * (int)sizeof(T));  // [WGM wm x 4 lane groups][2][BN]
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
@@ -475,12 +475,15 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(Conv
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  if (fstats && tid < 2 * BN) {
-    const int which = tid / BN, c = tid - which * BN;
-    float t = 0.f;
+  if (fstats) {
 #pragma unroll
-    for (int k = 0; k < 4 * WGM; ++k) t += red[(k * 2 + which) * BN + c];
-    a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
+    for (int o = tid; o < 2 * BN; o += 256) {
+      const int which = o / BN, c = o - which * BN;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4 * WGM; ++k) t += red[(k * 2 + which) * BN + c];
+      a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
+    }
   }
   if constexpr (EMODE == 1) return;
   constexpr int RPI = 256 / CPR;             // tile rows covered per iteration
@@ -670,8 +673,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void conv_igemm_kernel(Conv
       }
     }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid - which * BN;
+#pragma unroll
+    for (int o = tid; o < 2 * BN; o += 256) {
+      const int which = o / BN, c = o - which * BN;
       a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] =
           red4[which * BN + c] + red4[(2 + which) * BN + c] + red4[(4 + which) * BN + c] + red4[(6 + which) * BN + c];
     }
@@ -682,7 +686,8 @@ template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO 
 static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int stage = HALO ? NSTAGE * BN * 64 + 2 * (((BM / 16 + 2) * 24 + 63) / 64) * 4096 : NSTAGE * (BM + BN) * 64;
-  constexpr int epi = (BM < 128 ? BM : 128) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
+  constexpr int crows = BN > 128 ? 64 : 128;
+  constexpr int epi = (BM < crows ? BM : crows) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
   const int axf_lds = AXF ? 2 * (BM + BN) * 64 + 12 * a.KH * a.KW * a.Cin : 0;  // two slots + k1|k2|k3
   const int lds0 = stage > epi ? stage : epi;
   const int lds = AXF ? (axf_lds > epi ? axf_lds : epi) : lds0;
@@ -922,6 +927,23 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
   const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);
+  // 128x256 tiles for the channel-EXPANDING 1x1 layers: their A operand is re-read from L2 once per column tile
+  // and L2 -> LDS staging tops out near 8 TB/s (scripts/probes/dma_probe2.hip), so halving the column tiles halves
+  // the staged bytes; the channel-reducing ones get the taller 256x128 tile for the same reason (choose_bm).
+  {
+    const char* e = getenv("MAAI_CONV_BN");
+    const int fbn = e ? atoi(e) : 0;
+    if (!axf && dtype == MAAI_BF16 && bm == 128 && d->KH * d->KW == 1 && d->Cout % 256 == 0 && fbn != 128 && fbn != 64 &&
+        (emode == MAAI_EPI_STORE || emode == MAAI_EPI_DGRAD_REDUCE) &&
+        (fbn == 256 || (emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && d->Cout >= 2 * d->Cin && d->Cin >= 256 &&
+                        a.nMB * (long long)(d->Cout / 256) >= 512))) {
+      // measured in bench.py (B = 256, per launch): 256->1024 0.78 -> 0.74 ms, 512->2048 0.59 -> 0.56, 1024->2048/s2
+      // 1.09 -> 0.96; the read-modify-write epilogues (3.3 -> 4.1 ms on 128->512 with accumulate + sums) and K <= 128
+      // lose with the wider tile, so the shape rule covers the plain forward layers only
+      a.nNB = d->Cout / 256;
+      return launch_conv_n<bf16_t, 128, 256, 3>(a, st);
+    }
+  }
   if (axf) {
     return n128 ? launch_conv_p<bf16_t, 128, 128, 2, 6, true, false, true>(a, st) : launch_conv_p<bf16_t, 128, 64, 2, 6, true, false, true>(a, st);
   }

@@ -789,3 +789,45 @@ def test_persistent_pointwise_kernel_is_bit_identical(K, case):
     assert torch.equal(got["0"][1], got["1"][1])
     ref = F.conv2d(from_nhwc(x).double(), wq.float().cpu().permute(0, 3, 1, 2).double())
     np.testing.assert_allclose(from_nhwc(got["1"][0]).numpy(), ref.float().numpy(), **tol(torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 30, 30, 256, 1), (1, 512, 4, 4, 2048, 1), (2, 256, 15, 15, 512, 2), (3, 128, 17, 13, 512, 1)])
+def test_wide_column_tile_is_bit_identical(K, case):
+    """128x256 tiles (chosen by shape for the channel-expanding 1x1 layers; forced here with MAAI_CONV_BN=256) against
+    128x128 tiles: outputs, BatchNorm partial statistics, and the accumulate + mask + BN-backward-sums epilogue."""
+    n, cin, h, w, cout, stride = case
+    g = torch.Generator().manual_seed(23 + cin)
+    dt = torch.bfloat16
+    x = nhwc(torch.randn(n, cin, h, w, generator=g), dt)
+    wq = khwc(torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, dt)
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    ylow = nhwc(torch.randn(n, cout, oh, ow, generator=g), dt)
+    base = nhwc(torch.randn(n, cout, oh, ow, generator=g), dt)
+    mean, scale, shift = torch.randn(cout, generator=g).cuda(), torch.randn(cout, generator=g).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+    old = os.environ.get("MAAI_CONV_BN")
+    got = {}
+    try:
+        for bn in ("128", "256"):
+            os.environ["MAAI_CONV_BN"] = bn
+            y, part = K.conv2d(x, wq, stride, 0, 0, stats=True)
+            res = [y.clone(), part.clone()]
+            if stride == 1:
+                out = base.clone()
+                rows = K.conv2d_stats_rows(x, wq, 1, 0, 0, (oh, ow), (oh, ow))
+                p2 = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+                K.conv2d_store_reduce(x, wq, 1, 0, 0, out, p2, ylow, mean, scale, shift, None, grid_hw=(oh, ow), out_hw=(oh, ow), accumulate=True)
+                res += [out, K.reduce_partials(p2)]
+            torch.cuda.synchronize()
+            got[bn] = res
+    finally:
+        if old is None:
+            os.environ.pop("MAAI_CONV_BN", None)
+        else:
+            os.environ["MAAI_CONV_BN"] = old
+    assert torch.equal(got["128"][0], got["256"][0])
+    assert torch.equal(got["128"][1], got["256"][1])
+    if stride == 1:
+        assert torch.equal(got["128"][2], got["256"][2])
+        np.testing.assert_allclose(got["256"][3].cpu().numpy(), got["128"][3].cpu().numpy(), rtol=2e-5, atol=2e-4)
+    ref = F.conv2d(from_nhwc(x).double(), wq.float().cpu().permute(0, 3, 1, 2).double(), None, stride)
+    np.testing.assert_allclose(from_nhwc(got["256"][0]).numpy(), ref.float().numpy(), **tol(dt))
