@@ -97,7 +97,10 @@ typedef struct {
   const void* t;     /* BN_ACT: residual laid out like y (nullable); BWD_*: dz laid out like y;
                         DGRAD_REDUCE: the lower layer's raw conv output, laid out like y */
   int mask_bits;     /* DGRAD_REDUCE, bf16: relu_mask is the 1-bit mask of maai_bn_act_fwd_mask, not a tensor */
-  int reserved;
+  int sum_increment; /* DGRAD_REDUCE with d->accumulate: the partial sums are those of (stored value - previous content), i.e.
+                        of what this launch changes.  A strided second pass over a tensor whose first, dense pass reduced its
+                        own values (stride-2 downsample gradient added to the conv1 gradient) then completes the sums of the
+                        final tensor — pixels it does not touch contribute nothing — without a separate reduction pass */
   /* DGRAD_REDUCE on a pointwise bf16 layer, optional: the A operand of the GEMM is not x itself but
    * k1[c]*x - k2[c] - k3[c]*a2 per input channel c, i.e. the BatchNorm-backward apply of the layer whose gradient
    * this convolution propagates (x = dz, a2 = that layer's raw conv output), formed while staging instead of by a

@@ -73,6 +73,7 @@ struct ConvArgs {
   const float* ep2;
   const void* et;
   int mask_bits;  // mask is a 1-bit-per-element array (maai_bn_act_fwd_mask), EMODE 6 / 16-bit types only
+  int sum_incr;   // EMODE 6 with accumulate: reduce the sums of (stored - previous content) instead of the stored value
   int tilesX, tilesY;  // HALO kernels: 16-wide x BM/16-high output patches per image
   // AXF kernels: the A operand is k1*x - k2 - k3*a2 per input channel (BatchNorm-backward apply of the layer above),
   // computed while staging; a_out (nullable) receives it for the weight gradient
@@ -545,10 +546,9 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
         const int row = tid / CPR + (it0 + b) * RPI;
         Vec16<T> v;
         v.load(ct + row * LDC + chf * EPC);
-        float fv[NV];
+        float fv[NV], fo[NV];
         v.get(fv);
         if (a.accumulate) {
-          float fo[NV];
           vo[b].get(fo);
 #pragma unroll
           for (int e = 0; e < NV; ++e) fv[e] += fo[e];
@@ -572,6 +572,12 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
         v.set(fv);
         if constexpr (EMODE == 6) {
           v.get(fv);  // the rounded value being stored is what a separate reduction pass would read back
+          if (a.accumulate && a.sum_incr) {
+            // sums of the CHANGE this launch makes to the tensor (a strided second pass over a tensor whose first pass
+            // already reduced its own values): the two slabs add up to the sums of the final tensor exactly
+#pragma unroll
+            for (int e = 0; e < NV; ++e) fv[e] -= fo[e];
+          }
 #pragma unroll
           for (int e = 0; e < NV; ++e) {
             s1[e] += fv[e];
@@ -865,6 +871,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.ep2 = epi ? epi->p2 : nullptr;
   a.et = epi ? epi->t : nullptr;
   a.mask_bits = epi ? epi->mask_bits : 0;
+  a.sum_incr = epi ? epi->sum_increment : 0;
   a.a2 = epi ? epi->a2 : nullptr;
   a.ak1 = epi ? epi->ak1 : nullptr;
   a.ak2 = epi ? epi->ak2 : nullptr;

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 class ConvEpilogue(C.Structure):
     """maai_conv_epilogue"""
-    _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p), ("mask_bits", c_i), ("reserved", c_i),
+    _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p), ("mask_bits", c_i), ("sum_increment", c_i),
                 ("a2", c_p), ("ak1", c_p), ("ak2", c_p), ("ak3", c_p), ("a_out", c_p)]
 
 

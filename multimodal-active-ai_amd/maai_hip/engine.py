@@ -372,13 +372,16 @@ def axf_applies(rec, dz, below, need_dx=True):
     return ok
 
 
-def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None, axf=None):
+def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None, axf=None,
+               sum_increment=False):
     """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]; with ``relu_mask`` (= x,
     a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue.  ``below`` = the record of
     the unit whose output x is: the mask is then that unit's, and where every pixel of dx is written exactly once
     the unit's BN-backward sums are reduced in the same epilogue.  Returns (dx, fp64 sums [2C] or None).
     ``axf = (y, k1, k2, k3, dy_out)``: ``dy`` is really dz and the operand k1*dz - k2 - k3*y is formed in the launch
-    (pointwise layers with ``below``; see kernels.conv2d_store_reduce)."""
+    (pointwise layers with ``below``; see kernels.conv2d_store_reduce).  ``sum_increment`` (with ``accumulate``): the
+    returned sums are those of what this call ADDS to ``out`` — a strided pass that leaves pixels untouched can then
+    complete the sums a dense first pass produced."""
     n, cin = dy.shape[0], weight.shape[1]
     ih, iw = in_hw
     cls = dgrad_classes(k, stride, pad)
@@ -388,7 +391,8 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
         out = alloc((n, ih, iw, cin), dtype=dy.dtype, device=dy.device)
         if accumulate:
             raise MaaiError("conv_dgrad: accumulate needs an output tensor")
-    fuse = below is not None and _DGRAD_REDUCE["enabled"] and not empty and below.y is not None
+    incr = bool(sum_increment and accumulate)
+    fuse = below is not None and _DGRAD_REDUCE["enabled"] and (not empty or incr) and below.y is not None
     from_y = False
     if below is not None:
         if not below.relu:
@@ -422,7 +426,7 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
         K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], below.y, _reduce_mean(below),
                               below.scale if from_y else None, below.shift if from_y else None, relu_mask,
                               grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate,
-                              mask_bits=use_bits, axf=axf)
+                              mask_bits=use_bits, axf=axf, sum_increment=incr)
         r0 += nr
     return out, K.reduce_partials(slab)
 
@@ -476,7 +480,7 @@ def unit_bwd_coeffs(rec, dout, grads, dtype, presums=None):
 
 
 def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None, below=None,
-             presums=None, dy=None):
+             presums=None, dy=None, sum_increment=False):
     """Backward of unit_fwd.  CONVENTION: ``dout`` is already multiplied by the ReLU mask of this unit's
     output (the kernel that produced it folded ``* (out > 0)`` into its epilogue), so nothing here reads the
     forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way;
@@ -521,7 +525,7 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         dx, below_sums = None, None
     if need_dx:
         dx, below_sums = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate,
-                                    relu_mask=relu_mask, below=below)
+                                    relu_mask=relu_mask, below=below, sum_increment=sum_increment)
     return dx, below_sums
 
 
@@ -645,11 +649,21 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
         # (mask both: pixels the strided scatter never touches keep the first, already masked, value;
         #  m*(m*a + b) == m*(a + b) for a 0/1 mask).  The sums for ``prev`` can only ride the second pass, and
         #  only if it rewrites every pixel (stride-1 downsample); otherwise ``prev`` reduces them itself.
-        dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x, presums=s)
-        if prev is not None:
-            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
+        strided = rd.stride != 1
+        if prev is not None and strided and _DGRAD_REDUCE["enabled"] and prev.y is not None:
+            # stride-2 shortcut: the dense conv1 pass reduces the sums of what it stores, the strided pass those of what
+            # it adds on the pixels it touches (sum_increment) — together the sums of the final gradient
+            dx, sa = unit_bwd(r1, d, grads, dtype, below=prev, presums=s)
+            dx, sb = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd, sum_increment=True)
+            sp = sa + sb if (sa is not None and sb is not None) else None
+            if sp is None and (sa is not None or sb is not None):
+                raise MaaiError("block_bwd: the two passes of a strided shortcut must both reduce or both not")
         else:
-            dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x, dy=dyd)
+            dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x, presums=s)
+            if prev is not None:
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
+            else:
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x, dy=dyd)
     else:
         # identity shortcut: dx = dout + dgrad(conv1), accumulated in place in the conv epilogue
         if prev is not None:

@@ -144,7 +144,8 @@ def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=Non
 
 
 def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
-                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False, axf=None):
+                        grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False, axf=None,
+                        sum_increment=False):
     """conv2d(..., out=out) for a data gradient whose epilogue also reduces the BatchNorm-backward partial sums of
     the stored values g: rows of ``part`` [rows,2,Cout] get sum(g) and sum(g*(lower_y - mean)).  The ReLU mask is
     ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE).
@@ -160,7 +161,8 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
         raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
     epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
-                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0, 0)
+                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0,
+                       1 if (sum_increment and accumulate) else 0)
     if axf is not None:
         ya, k1, k2, k3, dyo = axf
         _gpu(ya, k1, k2, k3, dyo)

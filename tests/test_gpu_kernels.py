@@ -831,3 +831,39 @@ def test_wide_column_tile_is_bit_identical(K, case):
         np.testing.assert_allclose(got["256"][3].cpu().numpy(), got["128"][3].cpu().numpy(), rtol=2e-5, atol=2e-4)
     ref = F.conv2d(from_nhwc(x).double(), wq.float().cpu().permute(0, 3, 1, 2).double(), None, stride)
     np.testing.assert_allclose(from_nhwc(got["256"][0]).numpy(), ref.float().numpy(), **tol(dt))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_store_reduce_sum_increment_completes_the_sums(K, dtype):
+    """Stride-2 shortcut gradient: a dense pass reduces the sums of what it stores, a strided accumulate pass with
+    sum_increment those of what it adds; together they must equal the sums of the final tensor (exactly, up to the
+    fp32 order of partial sums), and the tensor must equal the plain two-pass result bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w = 2, 128, 13, 11
+    h2, w2 = (h + 1) // 2, (w + 1) // 2
+    xa = nhwc(torch.randn(n, 64, h, w, generator=g), dtype)
+    wa = khwc(torch.randn(c, 64, 1, 1, generator=g) / 8, dtype)
+    xb = nhwc(torch.randn(n, 256, h2, w2, generator=g), dtype)
+    wb = khwc(torch.randn(c, 256, 1, 1, generator=g) / 16, dtype)
+    ylow = nhwc(torch.randn(n, c, h, w, generator=g), dtype)
+    mask = nhwc(torch.randn(n, c, h, w, generator=g), dtype)
+    mean = torch.randn(c, generator=g).cuda()
+    # plain: dense masked pass, then strided accumulate + mask
+    want = torch.empty((n, h, w, c), dtype=dtype, device="cuda")
+    K.conv2d(xa, wa, 1, 0, 0, out=want, relu_mask=mask)
+    K.conv2d(xb, wb, 1, 0, 0, out=want, grid_hw=(h2, w2), out_hw=(h, w), out_stride=2, accumulate=True, relu_mask=mask)
+    # fused: both passes reduce
+    got = torch.empty_like(want)
+    r1 = K.conv2d_stats_rows(xa, wa, 1, 0, 0, (h, w), (h, w))
+    p1 = torch.zeros((r1, 2, c), dtype=torch.float32, device="cuda")
+    K.conv2d_store_reduce(xa, wa, 1, 0, 0, got, p1, ylow, mean, None, None, mask, grid_hw=(h, w), out_hw=(h, w))
+    r2 = K.conv2d_stats_rows(xb, wb, 1, 0, 0, (h2, w2), (h, w), 2)
+    p2 = torch.zeros((r2, 2, c), dtype=torch.float32, device="cuda")
+    K.conv2d_store_reduce(xb, wb, 1, 0, 0, got, p2, ylow, mean, None, None, mask, grid_hw=(h2, w2), out_hw=(h, w), out_stride=2,
+                          accumulate=True, sum_increment=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    sums = (K.reduce_partials(p1) + K.reduce_partials(p2)).cpu()
+    wf, yf = want.double().reshape(-1, c), ylow.double().reshape(-1, c)
+    ref = torch.cat([wf.sum(0), (wf * (yf - mean.double())).sum(0)]).cpu()
+    np.testing.assert_allclose(sums.numpy(), ref.numpy(), rtol=1e-4, atol=2e-3 if dtype == torch.float32 else 3e-2)
