@@ -33,7 +33,7 @@ for d in (ROOT, PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"))
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): dense bf16 MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r01_pmc_traffic_b256_v4.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_SUMMARY = "r01_pmc_traffic_b256_v5.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
 
 
 def parse():
