@@ -5,7 +5,7 @@ The reference wraps the model in DDP and immediately unwraps it
 a global-batch-4096 run needs that exchange, so it is supplied here: gradients
 are packed into a few large flat buckets (xGMI ring collectives are per-link
 bound — few big messages, not 161 small ones), summed with one all_reduce per
-bucket on a side stream, and averaged while unpacking."""
+bucket on a side stream, averaged with one kernel per bucket and handed back as views of the bucket."""
 import torch
 import torch.distributed as dist
 
@@ -60,12 +60,11 @@ class GradAllReduce(object):
             work.wait()
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
+            # one division per bucket; the gradients become views of the flat buffer (161 per-tensor kernels otherwise,
+            # each shorter than its launch).  The next backward replaces them before the buffer is packed again.
+            flat.div_(world)
             off = 0
             for p in bucket:
                 n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone().div_(world)
-                else:
-                    torch.div(g, world, out=p.grad)
+                p.grad = flat[off:off + n].view_as(p)
                 off += n
