@@ -74,6 +74,11 @@ long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
  * BWD_APPLY pass (dy = k1*dz - k2 - k3*y).  y is the bf16/f32-rounded accumulator, exactly the value the
  * unfused path would have stored.
  *
+ * BN_ACT is not limited to pointwise layers: with frozen statistics (eval-mode BatchNorm: feature extraction for the
+ * linear probe, Representation_Evaluation.py:598-712, and the frozen-backbone consumers) every convolution of the network
+ * can normalise, add the shortcut and activate in its own epilogue — one launch per conv-bn-relu unit, the raw output
+ * never reaches HBM.
+ *
  * DGRAD_REDUCE serves the data-gradient convolutions (any kernel size, scatter and accumulate allowed): the value
  * g this launch stores — conv (+ previous content when d->accumulate) times the ReLU mask — is the gradient dz
  * entering the BatchNorm of the layer below (resnet.py:101-104,121-128: conv -> bn -> relu), so the BN-backward

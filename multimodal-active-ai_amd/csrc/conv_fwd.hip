@@ -712,9 +712,11 @@ static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
 template <typename T, int BM, int BN, int NSTAGE, int EMODE>
 static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
   const bool pw = (a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_h == 0 && a.pad_w == 0 && a.OHg == a.IH && a.OWg == a.IW);
-  if constexpr (EMODE >= 1 && EMODE <= 4) {
+  if constexpr (EMODE == 1 || EMODE == 3 || EMODE == 4) {
+    // the recompute epilogues (statistics only, BN-backward reduce / apply) exist for pointwise layers; BN_ACT (2) is
+    // general: with frozen statistics any convolution can normalise, add the shortcut and activate in its epilogue
     if (!pw) {
-      maai_set_error("conv2d_igemm: fused epilogues are for pointwise stride-1 layers");
+      maai_set_error("conv2d_igemm: the statistics-only and BN-backward epilogues are for pointwise stride-1 layers");
       return MAAI_ERR_UNSUPPORTED;
     }
     return launch_conv_p<T, BM, BN, NSTAGE, EMODE, true>(a, st);
@@ -921,7 +923,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     }
   }
   ConvPlan plan = conv_plan(d, dtype);
-  if (axf) {  // 128-row tiles only (register-staged operand)
+  if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY)) {  // 128-row, row-staged tiles only
     plan.bm = 128;
     plan.halo = false;
     plan.nMB = (a.M + 127) / 128;
@@ -967,7 +969,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
 /* the same for a launch with an epilogue descriptor (the transformed-operand launches use 128-row tiles) */
 extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype) {
   if (!d) return 0;
-  if (epi && epi->a2) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  if (epi && (epi->a2 || (epi->mode >= MAAI_EPI_STATS_ONLY && epi->mode <= MAAI_EPI_BWD_APPLY)))
+    return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   return conv_plan(d, dtype).nMB;
 }
 

@@ -248,6 +248,7 @@ def _check_conv(conv):
 
 
 _DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
+_EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0"}
 
 
 def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None):
@@ -296,9 +297,13 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
             mom = 0.0
         mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
+        scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        if not keep and not defer and branch is None and _EVAL_FUSE["enabled"] and wq.shape[0] % 64 == 0:
+            # inference with frozen statistics: normalise (+ shortcut) + activate in the convolution's own epilogue,
+            # one launch per unit and no raw conv output in HBM (MAAI_EPI_BN_ACT on any kernel size)
+            return K.conv2d_bn_act(x, wq, scale, shift, residual, relu, stride, pad, pad_w), None
         if not fused:
             y = K.conv2d(x, wq, stride, pad, pad_w)
-        scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         mean = invstd = None
         count, world = x.numel() // x.shape[-1] if fused else y.numel() // y.shape[-1], 1
     if fused:

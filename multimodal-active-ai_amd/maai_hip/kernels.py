@@ -199,9 +199,10 @@ def _conv_fused(x, w, stride, pad_h, pad_w, mode, out, part, p0=None, p1=None, p
     return d
 
 
-def _stats_slab(x, w, stride, pad_h, pad_w):
+def _stats_slab(x, w, stride, pad_h, pad_w, mode=EPI_STATS_ONLY):
     d = make_desc(x, w, stride, pad_h, pad_w)
-    rows = lib().maai_conv2d_stats_rows(C.byref(d), _dt(x))
+    epi = ConvEpilogue(mode, 0, None, None, None, None)
+    rows = lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(x))
     return torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device), d
 
 

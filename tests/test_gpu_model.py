@@ -439,3 +439,33 @@ def test_block_recompute_matches_stored_activations(mods, prec):
         scale = gp.abs().max().item() + 1e-30
         assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, n
         assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), n
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_eval_mode_inference_fuses_bn_into_every_conv(mods, prec):
+    """Frozen-statistics inference (the feature-extraction consumer): every conv-bn-(add)-relu unit is ONE launch
+    (MAAI_EPI_BN_ACT on any kernel size, the raw conv output never stored) and gives bit-identical features to the
+    conv + separate BN pass sequence; the launch count drops accordingly."""
+    from maai_hip import engine, kernels as K
+    engine.set_precision(prec)
+    dtype = engine.compute_dtype()
+    m = _build(mods, "resnet50", 1, 2048 * 16, 4, (32, 32), 0.5)
+    m.train()
+    x = _u8(8, (4, 3, 32, 32)).float().cuda()
+    with torch.no_grad():
+        engine.backbone_fwd(m.f, x, dtype, keep=False)     # populate the running statistics
+    m.eval()
+    res = {}
+    for tag, flag in (("fused", True), ("plain", False)):
+        engine._EVAL_FUSE["enabled"] = flag
+        try:
+            with torch.no_grad(), K.profile() as prof:
+                feat, _ = engine.backbone_fwd(m.f, x, dtype, keep=False)
+            torch.cuda.synchronize()
+            res[tag] = (feat.float().cpu(), prof.table())
+        finally:
+            engine._EVAL_FUSE["enabled"] = True
+    assert torch.equal(res["fused"][0], res["plain"][0])
+    assert "bn_act_fwd" in res["plain"][1]
+    # only the four downsample blocks still run a (two-branch) BN pass of their own
+    assert res["fused"][1].get("bn_act_fwd", {"launches": 0})["launches"] <= 4
