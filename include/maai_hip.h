@@ -28,7 +28,7 @@ extern "C" {
 #define MAAI_BF16 0
 #define MAAI_F32 1
 
-#define MAAI_ABI_VERSION 1
+#define MAAI_ABI_VERSION 2
 
 int maai_abi_version(void);
 const char* maai_last_error(void);
@@ -116,6 +116,26 @@ typedef struct {
   const float* ak2;
   const float* ak3;
   void* a_out;
+  /* Normalise-on-load (mode STORE, dense, non-accumulating forward launches; any kernel size / stride):
+   * the A operand of the GEMM is not x itself but  act(x*xs[ci] + xt[ci])  per input channel ci, i.e. x is the RAW
+   * convolution output of the unit below and (xs, xt) its BatchNorm scale / shift (resnet.py:101-109: conv2 consumes
+   * relu(bn1(conv1(x))), conv3 consumes relu(bn2(..))).  The transform is applied to the staged operand in LDS, with
+   * the arithmetic of maai_bn_act_fwd (fp32 multiply, add, max, one rounding to the storage type) and with zero
+   * padding applied AFTER it, so the result is bit-identical to maai_bn_act_fwd followed by the plain launch — and
+   * the normalised activation never exists in HBM.  x_relu != 0 applies max(.,0).  NULL xs = plain operand.
+   * Pointwise stride-1 layers may join two raw tensors (resnet.py:126-133, `relu(bn3(y3) + identity)` consumed by
+   * the next block's conv1): A = act((x*xs + xt) + r(xb*xs2 + xt2)), xb laid out like x, r = rounding to the storage
+   * type (xs2 == NULL: xb is added as is — an identity shortcut), bit-identical to maai_bn_act_fwd2 / maai_bn_act_fwd
+   * with a residual.  x_out (nullable, laid out like x) receives the joined activation and x_bits (nullable, bf16
+   * only) its 1-bit ReLU mask in the format of maai_bn_act_fwd_mask, each written exactly once. */
+  const float* xs;
+  const float* xt;
+  int x_relu;
+  const void* xb;
+  const float* xs2;
+  const float* xt2;
+  void* x_out;
+  unsigned char* x_bits;
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);
@@ -130,6 +150,12 @@ int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const void* dy, fl
  * fewer add less fp32-atomic traffic; the host side measures once per shape and caches the choice. */
 int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype,
                             int target_blocks, void* stream);
+/* Same, with the x operand normalised on load: x is the RAW convolution output of the unit below and the gradient is
+ * taken with respect to the weights that multiplied act(x*xs[ci] + xt[ci]) (maai_conv_epilogue.xs/xt/x_relu: the
+ * forward pass never stored that activation).  Zero padding is applied after the transform.  Bit-identical to
+ * maai_bn_act_fwd followed by maai_conv2d_wgrad_tuned up to the order of the fp32 atomic adds.  xs == NULL: plain. */
+int maai_conv2d_wgrad_xf(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype, int target_blocks,
+                         const float* xs, const float* xt, int x_relu, void* stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm (training) — nn.BatchNorm2d / nn.SyncBatchNorm as norm_layer

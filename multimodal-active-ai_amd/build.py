@@ -36,6 +36,13 @@ def newest_dep():
 
 def compile_one(src):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    live = set(os.path.basename(p)[:-4] + ".o" for p in sources())
+    for f in os.listdir(OBJ):   # objects of sources that no longer exist
+        if f.endswith(".o") and f not in live:
+            try:
+                os.remove(os.path.join(OBJ, f))
+            except OSError:
+                pass
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "maai_hip.h")))
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
@@ -61,9 +68,13 @@ def build(force=False, verbose=True):
         for _, err in res:
             if err.strip():
                 sys.stderr.write(err)
-    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())   # never expose a half-written library to a concurrent loader
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed:\n" + r.stderr)
+    os.replace(tmp, LIB)
     return LIB
 
 

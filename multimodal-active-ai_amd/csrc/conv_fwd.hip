@@ -22,692 +22,7 @@
 // lines), optional read-modify-write accumulate and strided scatter (used by
 // the stride-2 data gradients), optional per-channel sum / sum-of-squares
 // partials for BatchNorm (one deterministic slab row per M-block, no atomics).
-#include "common.h"
-#include "maai_internal.h"
-#include "conv_pw.h"
-#include "conv_pp.h"
-#include <stdlib.h>
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  typedef bf16x8 frag;
-  __device__ static __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  typedef f32x4 frag;
-  // lane group g = lane>>4 holds k = 4g+j in element j of its 16-byte chunk; MFMA j
-  // consumes element j of both operands, i.e. a consistent permutation of K.
-  __device__ static __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
-    return c;
-  }
-};
-
-__device__ uint4 g_zero64[4];  // zero page for padding / out-of-range lanes of the LDS-DMA loads
-
-struct ConvArgs {
-  const void* x;
-  const void* w;
-  void* y;
-  float* stats;
-  const void* mask;  // optional: output *= (mask > 0), same layout as y (ReLU gradient of the tensor y is the gradient of)
-  long long M;
-  int N, IH, IW, Cin;
-  int Cout, KH, KW;
-  int stride, pad_h, pad_w;
-  int OHg, OWg;
-  int OH, OW;
-  int ostr, ooh, oow;
-  int accumulate;
-  int nMB, nNB;
-  // fused epilogues (maai_conv_epilogue): 0 store, 1 statistics only, 2 BN-apply(+residual)(+ReLU),
-  // 3 BN-backward reduce (partials of dz and dz*(y-mean)), 4 BN-backward apply (k1*dz - k2 - k3*y)
-  int emode, erelu;
-  const float* ep0;
-  const float* ep1;
-  const float* ep2;
-  const void* et;
-  int mask_bits;  // mask is a 1-bit-per-element array (maai_bn_act_fwd_mask), EMODE 6 / 16-bit types only
-  int sum_incr;   // EMODE 6 with accumulate: reduce the sums of (stored - previous content) instead of the stored value
-  int tilesX, tilesY;  // HALO kernels: 16-wide x BM/16-high output patches per image
-  // AXF kernels: the A operand is k1*x - k2 - k3*a2 per input channel (BatchNorm-backward apply of the layer above),
-  // computed while staging; a_out (nullable) receives it for the weight gradient
-  const void* a2;
-  const float* ak1;
-  const float* ak2;
-  const float* ak3;
-  void* a_out;
-};
-
-// EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
-// 6 = 5 plus the BN-backward partial sums of the stored gradient (MAAI_EPI_DGRAD_REDUCE).
-// PW: pointwise stride-1 layer (input pixel == output pixel): no row decode, no tap loop, no bounds tests.
-// HALO: 3x3 stride-1 same-size layers.  The M tile is a 16-wide x BM/16-high patch of output pixels of ONE image
-// and the A operand is its (BM/16+2) x 18 input halo, staged once per 32-channel chunk and read by all nine taps
-// at shifted pixel addresses, instead of nine separately staged 64-byte row sets: 2.3-3.4x fewer LDS-DMA bytes per
-// MFMA on the layers whose K loop is bound by exactly that traffic.  K order: chunk-major, tap-minor.
-// AXF (pointwise data gradients): A = k1*dz - k2 - k3*y — the BatchNorm-backward apply of the layer whose gradient
-// this convolution propagates — is computed on the way into LDS (global -> registers -> LDS, two slots) instead of
-// being written by a separate pass and read back; the transformed operand is also stored once (column tile 0) for
-// the weight gradient.  Same arithmetic, same bits as maai_bn_act_bwd_apply followed by the plain kernel.
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
-__global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_igemm_kernel(ConvArgs a) {
-  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-  constexpr int BK = 4 * EPC;               // 64-byte rows
-  constexpr int WGM = (BM == 256 && BN == 64) ? 4 : 2, WGN = 4 / WGM;  // wave grid: 2x2, or 4x1 for the 256x64 tile
-  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
-  constexpr int AR = BM / 64, BR = BN / 64;  // rows staged per thread
-  constexpr int STAGE = HALO ? BN * 64 : (BM + BN) * 64;  // bytes per ring buffer (HALO: weights only)
-  constexpr int TH = BM / 16;                // HALO: patch height; halo image = (TH+2) rows x 24 pixel slots (18 used)
-  constexpr int HROWS = (TH + 2) * 24;       //       pixel slots of 64 bytes
-  constexpr int NH = (HROWS + 63) / 64;      //       LDS-DMA instructions per thread per halo
-  constexpr int HSLOT = NH * 4096;           //       bytes per halo buffer (two of them after the weight ring)
-  constexpr int LDC = BN + EPC;              // C-tile row pitch (elements), 16-B padded
-  typedef typename Mma<T>::frag frag_t;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WGN, wn = wid % WGN;
-  const int logical = xcd_remap(blockIdx.x, a.nMB * a.nNB);
-  const int mb = logical / a.nNB, nb = logical - mb * a.nNB;
-  // HALO: patch origin of this tile
-  int hn = 0, oy0 = 0, ox0 = 0;
-  if constexpr (HALO) {
-    const int tpi = a.tilesX * a.tilesY;
-    hn = mb / tpi;
-    const int rem = mb - hn * tpi;
-    const int tyi = rem / a.tilesX;
-    oy0 = tyi * TH;
-    ox0 = (rem - tyi * a.tilesX) * 16;
-  }
-  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
-  const int K = a.KH * a.KW * a.Cin;
-  const int r0 = tid >> 2;
-  // LDS slot (row r, chunk tid&3) holds source chunk (tid&3) ^ swz(r): inverse swizzle on the SOURCE
-  const int chunk = (tid & 3) ^ (((r0 >> 3) & 1) << 1);
-
-  // ---- per-thread row decode (fixed for the whole K loop); 32-bit arithmetic (M < 2^31 is checked on the host),
-  //      and no decode at all for pointwise stride-1 layers where the input pixel IS the output pixel ----
-  long long abase[AR];
-  int ihb[AR], iwb[AR];
-  const unsigned ohw = (unsigned)(a.OHg * a.OWg);
-  constexpr bool pointwise = PW;
-#pragma unroll
-  for (int i = 0; i < (HALO ? 0 : AR); ++i) {
-    const long long m = (long long)mb * BM + r0 + 64 * i;
-    if (m < a.M) {
-      if (pointwise) {
-        ihb[i] = 0;
-        iwb[i] = 0;
-        abase[i] = m * a.Cin + chunk * EPC;
-      } else {
-        const unsigned mu = (unsigned)m;
-        const unsigned n = mu / ohw;
-        const unsigned rem = mu - n * ohw;
-        const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
-        ihb[i] = (int)oh * a.stride - a.pad_h;
-        iwb[i] = (int)ow * a.stride - a.pad_w;
-        abase[i] = (((long long)n * a.IH + ihb[i]) * a.IW + iwb[i]) * a.Cin + chunk * EPC;
-      }
-    } else {
-      ihb[i] = -(1 << 28);
-      iwb[i] = -(1 << 28);
-      abase[i] = 0;
-    }
-  }
-  const T* wp[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) wp[i] = w + (long long)(nb * BN + r0 + 64 * i) * K + chunk * EPC;
-
-  int kh = 0, kw = 0, c0 = 0;  // position of the NEXT stage to issue
-  const int KT = K / BK;
-  constexpr int NL = HALO ? BR : AR + BR;  // LDS-DMA instructions per thread per stage (HALO: the halo's own, once per
-                                           // nine stages, only make the counted waits below conservative)
-  const int widu = __builtin_amdgcn_readfirstlane(wid);
-  const T* zsrc = reinterpret_cast<const T*>(g_zero64);
-
-  auto issue_stage = [&](int kt, int slot) {
-    if constexpr (HALO) {
-      // kh = chunk counter, kw = tap counter of the NEXT stage to issue
-      if (kw == 0) {
-        char* hb = smem + NSTAGE * STAGE + (kh & 1) * HSLOT + widu * 1024;
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-          const int hp = r0 + 64 * i;                 // pixel slot of this lane
-          const int hy = hp / 24, hx = hp - hy * 24;
-          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-          const bool ok = hx < 18 && hy < TH + 2 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-          const int sc = (tid & 3) ^ (((hp >> 2) & 1) << 1);   // slot chunk (tid&3) holds source chunk sc
-          const T* src = ok ? x + (((long long)hn * a.IH + iy) * a.IW + ix) * a.Cin + kh * BK + sc * EPC : zsrc;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(hb + i * 4096), 16, 0, 0);
-        }
-      }
-      char* sb = smem + slot * STAGE + widu * 1024;
-      const long long boff = (long long)kw * a.Cin + kh * BK;
-#pragma unroll
-      for (int i = 0; i < BR; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + boff),
-                                         (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
-      if (++kw == 9) { kw = 0; ++kh; }
-      return;
-    }
-    const long long tapoff = PW ? (long long)kt * BK : ((long long)kh * a.IW + kw) * a.Cin + c0;
-    char* sa = smem + slot * STAGE + widu * 1024;
-    char* sb = sa + BM * 64;
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const bool ok = PW ? (ihb[i] >= 0) : ((unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW);
-      const T* src = ok ? (x + abase[i] + tapoff) : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sa + i * 4096), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + (long long)kt * BK),
-                                       (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
-    if constexpr (!PW) {
-      c0 += BK;
-      if (c0 >= a.Cin) {
-        c0 = 0;
-        if (++kw >= a.KW) { kw = 0; ++kh; }
-      }
-    }
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offset inside a 16-row group (swizzled): row = lane&15, chunk = lane>>4
-  const int frow = lane & 15;
-  const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) << 1)) << 4);
-
-  // HALO: per-lane fragment offsets inside a halo row for kw = 0, 1, 2 (24 slots per row keep bit 2 of the pixel
-  // slot, which the swizzle uses, a function of tx + kw alone); ctap / cchunk = tap and chunk of the stage being
-  // multiplied
-  int hoff[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int px = frow + q;
-    hoff[q] = px * 64 + (((lane >> 4) ^ (((px >> 2) & 1) << 1)) << 4);
-  }
-  int ctap = 0, cchunk = 0;
-  if constexpr (AXF) {
-    static_assert(!AXF || (PW && !HALO && sizeof(T) == 2 && BM == 128), "AXF: pointwise bf16 128-row tiles");
-    constexpr int SLOT = (BM + BN) * 64;
-    float* coef = reinterpret_cast<float*>(smem + 2 * SLOT);  // k1 | k2 | k3, K floats each
-    for (int i = tid; i < 3 * K; i += 256) coef[i] = i < K ? a.ak1[i] : (i < 2 * K ? a.ak2[i - K] : a.ak3[i - 2 * K]);
-    const T* __restrict__ y2 = reinterpret_cast<const T*>(a.a2);
-    T* __restrict__ dyo = reinterpret_cast<T*>(a.a_out);
-    const bool keep_dy = dyo != nullptr && nb == 0;
-    Vec16<T> rz[AR], ry[AR];
-    auto load_a = [&](int kt) {
-#pragma unroll
-      for (int i = 0; i < AR; ++i)
-        if (ihb[i] >= 0) {
-          rz[i].load(x + abase[i] + (long long)kt * BK);
-          ry[i].load(y2 + abase[i] + (long long)kt * BK);
-        }
-    };
-    auto issue_b = [&](int kt, int slot) {
-      char* sb = smem + slot * SLOT + BM * 64 + widu * 1024;
-#pragma unroll
-      for (int i = 0; i < BR; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[i] + (long long)kt * BK),
-                                         (__attribute__((address_space(3))) void*)(sb + i * 4096), 16, 0, 0);
-    };
-    auto store_a = [&](int kt, int slot) {
-      const float* c1 = coef + kt * BK + chunk * EPC;
-      float q1[8], q2[8], q3[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        q1[e] = c1[e];
-        q2[e] = c1[K + e];
-        q3[e] = c1[2 * K + e];
-      }
-#pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        float d[8], yy[8];
-        Vec16<T> v;
-        if (ihb[i] >= 0) {
-          rz[i].get(d);
-          ry[i].get(yy);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[e] = q1[e] * d[e] - q2[e] - q3[e] * yy[e];
-          v.set(d);
-          if (keep_dy) v.store(dyo + abase[i] + (long long)kt * BK);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) d[e] = 0.f;
-          v.set(d);
-        }
-        v.store(reinterpret_cast<T*>(smem + slot * SLOT + (r0 + 64 * i) * 64 + (tid & 3) * 16));
-      }
-    };
-    load_a(0);
-    issue_b(0, 0);
-    __syncthreads();  // coefficients are in LDS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_a(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-      const int slot = kt & 1;
-      if (kt + 1 < KT) {  // slot^1 was last read in iteration kt-1, whose closing barrier everyone has passed
-        load_a(kt + 1);
-        issue_b(kt + 1, slot ^ 1);
-      }
-      const char* sa = smem + slot * SLOT + (wm * WM) * 64 + foff;
-      const char* sb = smem + slot * SLOT + BM * 64 + (wn * WN) * 64 + foff;
-      frag_t af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * 16 * 64);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
-      if (kt + 1 < KT) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        store_a(kt + 1, slot ^ 1);
-      }
-      __syncthreads();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-  const int pre = KT < NSTAGE - 1 ? KT : NSTAGE - 1;
-  for (int s = 0; s < pre; ++s) issue_stage(s, s);
-
-  for (int kt = 0; kt < KT; ++kt) {
-    // stages kt+1 .. min(KT-1, kt+2) may stay in flight; stage kt must have landed
-    const int ahead = KT - 1 - kt;
-    if (NSTAGE >= 4 && ahead >= 2) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
-    } else if (NSTAGE >= 3 && ahead >= 1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    // everyone has finished reading slot (kt-1)%NSTAGE -> refill it with stage kt+NSTAGE-1
-    if (kt + NSTAGE - 1 < KT) issue_stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
-    const int slot = kt % NSTAGE;
-    const char* sa;
-    const char* sb;
-    if constexpr (HALO) {
-      const int ckh = ctap / 3, ckw = ctap - ckh * 3;
-      const int ho = ckw == 0 ? hoff[0] : (ckw == 1 ? hoff[1] : hoff[2]);
-      sa = smem + NSTAGE * STAGE + (cchunk & 1) * HSLOT + (wm * (WM / 16) + ckh) * (24 * 64) + ho;
-      sb = smem + slot * STAGE + (wn * WN) * 64 + foff;
-      if (++ctap == 9) { ctap = 0; ++cchunk; }
-    } else {
-      sa = smem + slot * STAGE + (wm * WM) * 64 + foff;
-      sb = smem + slot * STAGE + BM * 64 + (wn * WN) * 64 + foff;
-    }
-    frag_t af[TM], bfr[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * (HALO ? 24 * 64 : 16 * 64));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
-  }
-  }
-  __syncthreads();  // all DMA retired (vmcnt(0) above); the ring is now reused as the C tile
-  if constexpr (HALO) {
-    // patch rows / columns outside the image hold sums over real neighbours: zero them so that neither the
-    // statistics nor anything else sees them (their stores are skipped below)
-    if (oy0 + TH > a.OH || ox0 + 16 > a.OW) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const bool rowok = oy0 + wm * (WM / 16) + i < a.OH;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = rowok && (ox0 + (lane >> 4) * 4 + r < a.OW);
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            if (!ok) acc[i][j][r] = 0.f;
-        }
-      }
-    }
-  }
-
-  // ---- epilogue ----
-  T* ct = reinterpret_cast<T*>(smem);
-  constexpr int CROWS = BN > 128 ? 64 : 128;  // rows the C tile holds; taller (or 256-column) tiles drain in phases
-  constexpr int NPH = BM / CROWS > 0 ? (BM + CROWS - 1) / CROWS : 1;
-  float* red = reinterpret_cast<float*>(smem + (BM < CROWS ? BM : CROWS) * LDC * (int)sizeof(T));  // [WGM wm x 4 lane groups][2][BN]
-  T* __restrict__ y = reinterpret_cast<T*>(a.y);
-  constexpr int CPR = BN / EPC;  // 16-byte chunks per tile row
-  constexpr int NV = Vec16<T>::N;
-  const bool dense = (a.ostr == 1 && a.ooh == 0 && a.oow == 0 && a.OHg == a.OH && a.OWg == a.OW);
-  const int chf = tid % CPR;                 // this thread's chunk column (256 % CPR == 0)
-  const int cch0 = nb * BN + chf * EPC;      // its first output channel
-  constexpr bool FUSED = EMODE >= 2 && EMODE <= 4;  // (EMODE 5 = accumulate / mask store, not a BN epilogue)
-  constexpr bool PARAMS = FUSED || EMODE == 6;
-  constexpr int NQ = PARAMS ? NV : 1;        // per-channel epilogue parameters live only in the fused kernels
-  float q0[NQ], q1[NQ], q2[NQ], s1[NQ], s2[NQ];
-  if constexpr (PARAMS) {
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-      q0[e] = a.ep0 ? a.ep0[cch0 + e] : (EMODE == 2 ? 1.f : 0.f);
-      q1[e] = ((EMODE == 2 || EMODE == 4 || EMODE == 6) && a.ep1) ? a.ep1[cch0 + e] : 0.f;
-      q2[e] = ((EMODE == 4 || EMODE == 6) && a.ep2) ? a.ep2[cch0 + e] : 0.f;
-      s1[e] = 0.f;
-      s2[e] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int ph = 0; ph < NPH; ++ph) {
-  if (ph > 0) __syncthreads();  // the previous phase's readers are done with the C tile
-  if constexpr (EMODE == 1) {
-    // statistics only: the accumulators never leave the registers
-  } else if constexpr (sizeof(T) == 2) {
-    // The short-K layers are VALU-bound in this epilogue (measured: ~600 vector instructions per wave against
-    // 32 MFMAs), so the C tile is written with the fewest vector instructions: one v_cvt_pk_bf16_f32 per row
-    // pair and four 16-bit LDS stores (low half / d16_hi) per 16x16 tile — no lane exchange, no selects, and
-    // every address is one per-lane base plus a compile-time offset.
-    unsigned short* cbase = reinterpret_cast<unsigned short*>(smem) + ((wm * WM) % CROWS + (lane >> 4) * 4) * LDC + wn * WN + (lane & 15);
-    if (NPH == 1 || (wm * WM) / CROWS == ph) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const f32x4 v = acc[i][j];
-          const uint32_t p01 = pack_bf16x2(v[0], v[1]);
-          const uint32_t p23 = pack_bf16x2(v[2], v[3]);
-          // one v_cvt_pk per row PAIR: the low half goes out with ds_write_b16, the high half with its d16_hi form
-          // (left to the compiler this became one conversion per value)
-          const uint32_t ca = (uint32_t)(uintptr_t)cbase;   // one base register; the tile position is an immediate offset
-          asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(ca), "v"(p01),
-                       "n"((i * 16 * LDC + j * 16) * 2), "n"((i * 16 * LDC + j * 16) * 2 + LDC * 2)
-                       : "memory");
-          asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(ca), "v"(p23),
-                       "n"((i * 16 * LDC + j * 16) * 2 + LDC * 4), "n"((i * 16 * LDC + j * 16) * 2 + LDC * 6)
-                       : "memory");
-        }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ml = (wm * WM) % CROWS + i * 16 + (lane >> 4) * 4 + r;
-          if (NPH > 1 && (wm * WM) / CROWS != ph) continue;
-          const int nl = wn * WN + j * 16 + (lane & 15);
-          Store<T>::st(ct + ml * LDC + nl, acc[i][j][r]);
-        }
-  }
-  const bool fstats = a.stats && EMODE != 3 && EMODE != 6 && ph == 0;
-  if (fstats) {
-    // per lane: column n = j*16 + (lane&15), rows of its lane group; the 8 (wm, lane-group) partials per column
-    // meet in LDS (cheaper than 16 cross-row shuffles per wave)
-    float* sred = red + ((wm * 4 + (lane >> 4)) * 2) * BN + wn * WN + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): two rows per instruction, half the vector-issue slots
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
-        s2 += lo;
-        q2 = __builtin_elementwise_fma(lo, lo, q2);
-        s2 += hi;
-        q2 = __builtin_elementwise_fma(hi, hi, q2);
-      }
-      sred[j * 16] = s2.x + s2.y;
-      sred[BN + j * 16] = q2.x + q2.y;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (fstats) {
-#pragma unroll
-    for (int o = tid; o < 2 * BN; o += 256) {
-      const int which = o / BN, c = o - which * BN;
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4 * WGM; ++k) t += red[(k * 2 + which) * BN + c];
-      a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
-    }
-  }
-  if constexpr (EMODE == 1) return;
-  constexpr int RPI = 256 / CPR;             // tile rows covered per iteration
-  const bool full = dense && ((long long)(mb + 1) * BM <= a.M);
-  const long long off0 = ((long long)mb * BM + ph * CROWS + tid / CPR) * a.Cout + nb * BN + chf * EPC;
-  const long long ostep = (long long)RPI * a.Cout;
-  if constexpr (EMODE == 5 || EMODE == 6) {
-    // Read-modify-write epilogues.  The stores of one iteration may alias the loads of the next as far as the
-    // compiler can tell, which would serialise eight load -> store round trips per thread; so the global loads
-    // of NB iterations (previous content, the lower layer's y, the mask) are issued together, then consumed.
-    constexpr int NIT = (BM < CROWS ? BM : CROWS) / RPI;
-    constexpr int NB = (NIT % 4 == 0 && BM < 256) ? 4 : (NIT % 2 == 0 ? 2 : 1);  // (4 would spill under the 256-row tile)
-#pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += NB) {
-      long long ooffs[NB];
-      bool ok[NB];
-      Vec16<T> vo[NB], vy[NB], vm[NB];
-      unsigned mb8[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int it = it0 + b;
-        const int row = tid / CPR + it * RPI;
-        long long ooff = off0 + it * ostep;
-        ok[b] = true;
-        if constexpr (HALO) {
-          const int R = ph * CROWS + row;
-          const int oy = oy0 + (R >> 4), ox = ox0 + (R & 15);
-          ok[b] = oy < a.OH && ox < a.OW;
-          ooff = (((long long)hn * a.OH + oy) * a.OW + ox) * a.Cout + nb * BN + chf * EPC;
-        } else if (!full) {
-          const long long m = (long long)mb * BM + ph * CROWS + row;
-          ok[b] = m < a.M;
-          long long opix = m;
-          if (!dense) {
-            const unsigned mu = (unsigned)m;
-            const unsigned n = mu / ohw;
-            const unsigned rem = mu - n * ohw;
-            const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
-            opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
-          }
-          ooff = opix * a.Cout + nb * BN + chf * EPC;
-        }
-        ooffs[b] = ooff;
-        mb8[b] = 0;
-        if (ok[b]) {
-          if (a.accumulate) vo[b].load(y + ooff);
-          if constexpr (EMODE == 6) vy[b].load(reinterpret_cast<const T*>(a.et) + ooff);
-          if (a.mask) {
-            if (EMODE == 6 && NV == 8 && a.mask_bits)
-              mb8[b] = reinterpret_cast<const unsigned char*>(a.mask)[ooff >> 3];
-            else
-              vm[b].load(reinterpret_cast<const T*>(a.mask) + ooff);
-          }
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (!ok[b]) continue;
-        const int row = tid / CPR + (it0 + b) * RPI;
-        Vec16<T> v;
-        v.load(ct + row * LDC + chf * EPC);
-        float fv[NV], fo[NV];
-        v.get(fv);
-        if (a.accumulate) {
-          vo[b].get(fo);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) fv[e] += fo[e];
-        }
-        float fy[NV];
-        if constexpr (EMODE == 6) vy[b].get(fy);
-        if (a.mask) {
-          if (EMODE == 6 && NV == 8 && a.mask_bits) {
-#pragma unroll
-            for (int e = 0; e < NV; ++e) fv[e] = ((mb8[b] >> e) & 1u) ? fv[e] : 0.f;
-          } else {
-            float fm[NV];
-            vm[b].get(fm);
-#pragma unroll
-            for (int e = 0; e < NV; ++e) fv[e] = fm[e] > 0.f ? fv[e] : 0.f;
-          }
-        } else if (EMODE == 6 && a.ep1 && a.ep2) {  // the lower layer's ReLU output is positive exactly where y*scale + shift is
-#pragma unroll
-          for (int e = 0; e < NV; ++e) fv[e] = (fy[e] * q1[e] + q2[e]) > 0.f ? fv[e] : 0.f;
-        }
-        v.set(fv);
-        if constexpr (EMODE == 6) {
-          v.get(fv);  // the rounded value being stored is what a separate reduction pass would read back
-          if (a.accumulate && a.sum_incr) {
-            // sums of the CHANGE this launch makes to the tensor (a strided second pass over a tensor whose first pass
-            // already reduced its own values): the two slabs add up to the sums of the final tensor exactly
-#pragma unroll
-            for (int e = 0; e < NV; ++e) fv[e] -= fo[e];
-          }
-#pragma unroll
-          for (int e = 0; e < NV; ++e) {
-            s1[e] += fv[e];
-            s2[e] += fv[e] * (fy[e] - q0[e]);
-          }
-        }
-        v.store(y + ooffs[b]);
-      }
-    }
-  } else {
-#pragma unroll
-  for (int it = 0; it < (BM < CROWS ? BM : CROWS) / RPI; ++it) {
-    const int row = tid / CPR + it * RPI, ch = chf;
-    long long opix;
-    long long ooff_fast = off0 + it * ostep;
-    if constexpr (HALO) {
-      const int R = ph * CROWS + row;
-      const int oy = oy0 + (R >> 4), ox = ox0 + (R & 15);
-      if (oy >= a.OH || ox >= a.OW) continue;
-      ooff_fast = (((long long)hn * a.OH + oy) * a.OW + ox) * a.Cout + nb * BN + ch * EPC;
-    } else if (!full) {
-      const long long m = (long long)mb * BM + ph * CROWS + row;
-      if (m >= a.M) continue;
-      opix = m;
-      if (!dense) {
-        const unsigned mu = (unsigned)m;
-        const unsigned n = mu / ohw;
-        const unsigned rem = mu - n * ohw;
-        const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
-        opix = ((long long)n * a.OH + oh * a.ostr + a.ooh) * a.OW + ow * a.ostr + a.oow;
-      }
-      ooff_fast = opix * a.Cout + nb * BN + ch * EPC;
-    }
-    const long long ooff = ooff_fast;
-    T* dst = y + ooff;
-    Vec16<T> v;
-    v.load(ct + row * LDC + ch * EPC);
-    if constexpr (FUSED) {
-      float fv[NV];
-      v.get(fv);
-      if constexpr (EMODE == 2) {  // out = act(y*scale + shift (+ residual))
-#pragma unroll
-        for (int e = 0; e < NV; ++e) fv[e] = fv[e] * q0[e] + q1[e];
-        if (a.et) {
-          Vec16<T> r;
-          r.load(reinterpret_cast<const T*>(a.et) + ooff);
-          float fr[NV];
-          r.get(fr);
-#pragma unroll
-          for (int e = 0; e < NV; ++e) fv[e] += fr[e];
-        }
-        if (a.erelu) {
-#pragma unroll
-          for (int e = 0; e < NV; ++e) fv[e] = fmaxf(fv[e], 0.f);
-        }
-        v.set(fv);
-        v.store(dst);
-      } else {
-        Vec16<T> dzv;
-        dzv.load(reinterpret_cast<const T*>(a.et) + ooff);
-        float dz[NV];
-        dzv.get(dz);
-        if constexpr (EMODE == 3) {  // sums of dz and dz*(y-mean)
-#pragma unroll
-          for (int e = 0; e < NV; ++e) {
-            s1[e] += dz[e];
-            s2[e] += dz[e] * (fv[e] - q0[e]);
-          }
-        } else {  // dy = k1*dz - k2 - k3*y
-#pragma unroll
-          for (int e = 0; e < NV; ++e) fv[e] = q0[e] * dz[e] - q1[e] - q2[e] * fv[e];
-          v.set(fv);
-          v.store(dst);
-        }
-      }
-      continue;
-    }
-    v.store(dst);
-  }
-  }
-  }  // phases
-  if constexpr (EMODE == 3 || EMODE == 6) {
-    // lanes l, l+CPR, l+2CPR.. of a wave hold the same channels: butterfly, then the four waves through LDS
-#pragma unroll
-    for (int e = 0; e < NV; ++e) {
-#pragma unroll
-      for (int o = CPR; o < 64; o <<= 1) {
-        s1[e] += __shfl_xor(s1[e], o);
-        s2[e] += __shfl_xor(s2[e], o);
-      }
-    }
-    __syncthreads();  // everyone is done reading the C tile / the forward-statistics scratch
-    float* red4 = reinterpret_cast<float*>(smem);  // [4 waves][2][BN], reuses the C tile
-    if (lane < CPR) {
-#pragma unroll
-      for (int e = 0; e < NV; ++e) {
-        red4[(wid * 2 + 0) * BN + lane * EPC + e] = s1[e];
-        red4[(wid * 2 + 1) * BN + lane * EPC + e] = s2[e];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int o = tid; o < 2 * BN; o += 256) {
-      const int which = o / BN, c = o - which * BN;
-      a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] =
-          red4[which * BN + c] + red4[(2 + which) * BN + c] + red4[(4 + which) * BN + c] + red4[(6 + which) * BN + c];
-    }
-  }
-}
-
-template <typename T, int BM, int BN, int NSTAGE, int EMODE, bool PW, bool HALO = false, bool AXF = false>
-static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
-  constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int stage = HALO ? NSTAGE * BN * 64 + 2 * (((BM / 16 + 2) * 24 + 63) / 64) * 4096 : NSTAGE * (BM + BN) * 64;
-  constexpr int crows = BN > 128 ? 64 : 128;
-  constexpr int epi = (BM < crows ? BM : crows) * (BN + EPC) * (int)sizeof(T) + 32 * BN * (int)sizeof(float);
-  const int axf_lds = AXF ? 2 * (BM + BN) * 64 + 12 * a.KH * a.KW * a.Cin : 0;  // two slots + k1|k2|k3
-  const int lds0 = stage > epi ? stage : epi;
-  const int lds = AXF ? (axf_lds > epi ? axf_lds : epi) : lds0;
-  static int attr_lds = -1;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_lds = lds;
-  }
-  const long long grid = (long long)a.nMB * a.nNB;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF>), dim3((unsigned)grid), dim3(256), lds, st, a);
-  MAAI_CHECK_LAUNCH();
-  return MAAI_OK;
-}
+#include "conv_igemm.h"
 
 template <typename T, int BM, int BN, int NSTAGE, int EMODE>
 static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
@@ -879,6 +194,23 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.ak2 = epi ? epi->ak2 : nullptr;
   a.ak3 = epi ? epi->ak3 : nullptr;
   a.a_out = epi ? epi->a_out : nullptr;
+  a.xs = epi ? epi->xs : nullptr;
+  a.xt = epi ? epi->xt : nullptr;
+  a.x_relu = epi ? epi->x_relu : 0;
+  a.xb = epi ? epi->xb : nullptr;
+  a.xs2 = epi ? epi->xs2 : nullptr;
+  a.xt2 = epi ? epi->xt2 : nullptr;
+  a.x_out = epi ? epi->x_out : nullptr;
+  a.x_bits = epi ? epi->x_bits : nullptr;
+  if (a.xs || a.xb) {
+    MAAI_CHECK_ARG(a.xs && a.xt && emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && d->out_stride == 1 && !a.a2,
+                   "conv2d_igemm: the normalised-on-load operand needs xs and xt and a plain dense forward launch");
+    const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+    MAAI_CHECK_ARG(!a.xb || pw1, "conv2d_igemm: the two-tensor join on load is for pointwise stride-1 layers");
+    MAAI_CHECK_ARG((a.xs2 == nullptr) == (a.xt2 == nullptr) && (a.xb || (!a.xs2 && !a.x_out && !a.x_bits)),
+                   "conv2d_igemm: xs2/xt2 come in pairs and, like x_out/x_bits, belong to the two-tensor join");
+    MAAI_CHECK_ARG(!a.x_bits || (a.x_out && dtype == MAAI_BF16), "conv2d_igemm: the 1-bit mask of the joined activation is for bf16 x_out");
+  }
   const bool axf = a.a2 != nullptr;
   if (axf) {
     const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
@@ -890,49 +222,31 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.M = (long long)d->N * d->OHg * d->OWg;
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // Pointwise stride-1 layers with a dense output CAN go to the direct-epilogue kernel (conv_pw.hip).  Measured
-  // on MI355X (bench.py, B = 256): 589.8 vs 596.2 images/s plain, 581.0 vs 576.8 with the fused conv+BN units —
-  // the LDS-transposed full-row stores of this file beat its 64-byte-per-pixel direct stores once the epilogue
-  // VALU diet was in, so it is opt-in (MAAI_PW_DIRECT=1, read per call so tests can toggle it).
-  const bool pw_direct = getenv("MAAI_PW_DIRECT") && atoi(getenv("MAAI_PW_DIRECT")) == 1;
-  const bool pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH &&
-                  d->OWg == d->IW && d->out_stride == 1 && d->out_off_h == 0 && d->out_off_w == 0 && d->OH == d->OHg &&
-                  d->OW == d->OWg;
-  if (pw && pw_direct && emode != MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && choose_bm(d, dtype) == 128) {
-    PwArgs p;
-    p.x = x; p.w = w; p.y = y; p.stats = stats_partial; p.mask = relu_mask; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
-    p.accumulate = d->accumulate; p.nMB = p.nNB = 0; p.erelu = a.erelu; p.ep0 = a.ep0; p.ep1 = a.ep1; p.ep2 = a.ep2; p.et = a.et;
-    return maai_pw_conv_launch(p, emode, st);
-  }
-  // Forward pointwise layers with a K loop of 4+ steps CAN go to the persistent, software-pipelined kernel (conv_pp.hip:
-  // two resident workgroups per CU walk the tiles, the LDS-DMA ring runs across tile boundaries).  Bit-identical, but
-  // measured slower on MI355X (scripts/conv_pw_ab.py, B = 256: 256->1024 0.78 -> 0.95 ms, 512->2048 0.58 -> 0.75 ms):
-  // whatever holds these layers at 23 % of the matrix pipe, it is not the per-tile latency chain.  Opt-in:
-  // MAAI_PW_PERSIST=1 (read per call).
-  {
-    const char* e = getenv("MAAI_PW_PERSIST");
-    const int forced = e ? atoi(e) : 0;
-    const long long tiles = ((a.M + 127) / 128) * (d->Cout / 128);
-    if (pw && !axf && forced == 1 && dtype == MAAI_BF16 && emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && stats_partial &&
-        d->Cout % 128 == 0 && d->Cin % 32 == 0 && d->Cin / 32 >= 4 && choose_bm(d, dtype) == 128 && tiles < (1ll << 31)) {
-      PpArgs p;
-      p.x = reinterpret_cast<const bf16_t*>(x); p.w = reinterpret_cast<const bf16_t*>(w); p.y = reinterpret_cast<bf16_t*>(y);
-      p.stats = stats_partial; p.M = a.M; p.Cin = d->Cin; p.Cout = d->Cout;
-      p.nMB = (int)((a.M + 127) / 128); p.nNB = d->Cout / 128; p.ntiles = (int)tiles;
-      return maai_pp_conv_launch(p, st);
-    }
-  }
   ConvPlan plan = conv_plan(d, dtype);
   if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY)) {  // 128-row, row-staged tiles only
     plan.bm = 128;
     plan.halo = false;
     plan.nMB = (a.M + 127) / 128;
   }
+  const bool xf = a.xs != nullptr;
+  if (xf && plan.bm == 64) {  // (a tuning knob's tile the transformed-operand kernels are not built for)
+    plan.bm = 128;
+    plan.nMB = (a.M + 127) / 128;
+  }
   const int bm = plan.bm;
   a.nMB = (int)plan.nMB;
   a.tilesX = plan.tilesX;
   a.tilesY = plan.tilesY;
-  if (plan.halo) return d->Cout % 128 == 0 ? (a.nNB = d->Cout / 128, launch_halo<128>(a, st)) : (a.nNB = d->Cout / 64, launch_halo<64>(a, st));
+  ConvSel sel;
+  sel.dtype = dtype; sel.bm = bm; sel.halo = plan.halo; sel.nstage = 3;
+  sel.pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+  if (plan.halo) {
+    const bool h128 = d->Cout % 128 == 0;
+    a.nNB = d->Cout / (h128 ? 128 : 64);
+    sel.bn = h128 ? 128 : 64;
+    if (xf) return maai_conv_xf_launch(a, sel, st);
+    return h128 ? launch_halo<128>(a, st) : launch_halo<64>(a, st);
+  }
   static const int force_bn = getenv("MAAI_CONV_BN") ? atoi(getenv("MAAI_CONV_BN")) : 0;  // experiment knob
   const bool n128 = d->Cout % 128 == 0 && !(force_bn == 64 && d->KH * d->KW * d->Cin <= 128);
   a.nNB = d->Cout / (n128 ? 128 : 64);
@@ -950,8 +264,15 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
       // 1.09 -> 0.96; the read-modify-write epilogues (3.3 -> 4.1 ms on 128->512 with accumulate + sums) and K <= 128
       // lose with the wider tile, so the shape rule covers the plain forward layers only
       a.nNB = d->Cout / 256;
+      sel.bn = 256;
+      if (xf) return maai_conv_xf_launch(a, sel, st);
       return launch_conv_n<bf16_t, 128, 256, 3>(a, st);
     }
+  }
+  if (xf) {
+    sel.bn = n128 ? 128 : 64;
+    sel.nstage = (bm == 128 && d->KH * d->KW * d->Cin * (dtype == MAAI_BF16 ? 2 : 4) / 64 <= 2) ? 2 : 3;
+    return maai_conv_xf_launch(a, sel, st);
   }
   if (axf) {
     return n128 ? launch_conv_p<bf16_t, 128, 128, 2, 6, true, false, true>(a, st) : launch_conv_p<bf16_t, 128, 64, 2, 6, true, false, true>(a, st);
@@ -971,7 +292,9 @@ extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const
   if (!d) return 0;
   if (epi && (epi->a2 || (epi->mode >= MAAI_EPI_STATS_ONLY && epi->mode <= MAAI_EPI_BWD_APPLY)))
     return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
-  return conv_plan(d, dtype).nMB;
+  const ConvPlan p = conv_plan(d, dtype);
+  if (epi && epi->xs && p.bm == 64) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  return p.nMB;
 }
 
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {

@@ -27,9 +27,46 @@ struct WgradArgs {
   int N, IH, IW, Cin, Cout, KH, KW, stride, pad_h, pad_w, OH, OW;
   int nCoB, nCiB, nTap;
   int pix_per_split;
+  // XF: the x operand is act(x*xs[ci] + xt[ci]) — x is the RAW convolution output of the unit below and the weight
+  // gradient needs that unit's normalised activation, which the forward pass never stored (conv_igemm.h, XF)
+  const float* xs;
+  const float* xt;
+  int x_relu;
 };
 
-template <typename T, int BCO, int BCI>
+// act(v*s + t) on a 16-byte chunk, with the arithmetic (and rounding) of maai_bn_act_fwd
+template <typename T>
+__device__ __forceinline__ void xf_apply(Vec16<T>& v, const float* cs, const float* ct, int relu) {
+  constexpr int E = Vec16<T>::N;
+  float f[E];
+  v.get(f);
+#pragma unroll
+  for (int e = 0; e < E; ++e) f[e] *= cs[e];
+#pragma unroll
+  for (int e = 0; e < E; ++e) f[e] += ct[e];
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e], 0.f);
+  }
+  v.set(f);
+}
+
+template <bool ASM>
+__device__ __forceinline__ void wdma16(const void* gsrc, char* lds_dst) {
+  if constexpr (ASM) {  // invisible to hipcc, which would order every LDS access behind all LDS-DMA in flight (conv_igemm.h, dma16)
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+  } else {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+  }
+}
+
+template <typename T, int BCO, int BCI, bool XF = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -77,8 +114,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int n = m / ohw, rem = m - n * ohw;
         const int oh = rem / a.OW, ow = rem - oh * a.OW;
         const int ih = oh * a.stride - a.pad_h + kh, iw = ow * a.stride - a.pad_w + kw;
-        if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+        if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
           v = *reinterpret_cast<const uint4*>(x + (((long long)n * a.IH + ih) * a.IW + iw) * a.Cin + ci0 + ch * EPC);
+          if constexpr (XF) {  // padding stays zero: the convolution pads the activation
+            Vec16<T> t;
+            t.raw = __builtin_bit_cast(decltype(t.raw), v);
+            xf_apply<T>(t, a.xs + ci0 + ch * EPC, a.xt + ci0 + ch * EPC, a.x_relu);
+            v = __builtin_bit_cast(uint4, t.raw);
+          }
+        }
       }
       rx[i] = v;
     }
@@ -195,7 +239,7 @@ __device__ __forceinline__ int swz(int row) {
   return BC >= 128 ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
 }
 
-template <int BCO, int BCN, int NWM, int NWN>
+template <int BCO, int BCN, int NWM, int NWN, bool XF = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a) {
   constexpr int PK = 32, NSTAGE = 3, NT = 64 * NWM * NWN;
   constexpr int RBY = BCO * 2, RBX = BCN * 2;           // row bytes
@@ -260,6 +304,19 @@ __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a)
     poh[i] = rem / a.OW;
     pow_[i] = rem - poh[i] * a.OW;
   }
+  // XF: per-slot channel coefficients (fixed for the whole kernel) and, per ring slot, which of this thread's x chunks
+  // hold real data (bit slot*NLX + i): out-of-range rows / taps / columns source the zero page and must stay zero
+  float xcs[XF ? NLX : 1][8], xct[XF ? NLX : 1][8];
+  unsigned okbits = 0;
+  if constexpr (XF) {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xcs[i][e] = xcol_ok[i] ? a.xs[xci[i] + e] : 0.f;
+        xct[i][e] = xcol_ok[i] ? a.xt[xci[i] + e] : 0.f;
+      }
+  }
 
   auto issue_stage = [&](int p0, int slot) {
     char* sy = smem + slot * STAGE + widu * 1024;
@@ -268,9 +325,9 @@ __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a)
     for (int i = 0; i < NLY; ++i) {
       const int m = p0 + yrow[i];
       const bf16_t* src = (m < pe) ? dy + (long long)m * a.Cout + yoff[i] : zsrc;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sy + i * (NT * 16)), 16, 0, 0);
+      wdma16<XF>(src, sy + i * (NT * 16));
     }
+    if constexpr (XF) okbits &= ~(((1u << NLX) - 1u) << (slot * NLX));
 #pragma unroll
     for (int i = 0; i < NLX; ++i) {
       const int m = p0 + xrow[i];
@@ -284,8 +341,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a)
             src = x + (((long long)pn[i] * a.IH + ih) * a.IW + iw) * a.Cin + xci[i];
         }
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sx + i * (NT * 16)), 16, 0, 0);
+      if constexpr (XF) okbits |= (src != zsrc ? 1u : 0u) << (slot * NLX + i);
+      wdma16<XF>(src, sx + i * (NT * 16));
       if (!dense) {  // advance this slot's pixel by PK
         pow_[i] += PK;
         while (pow_[i] >= a.OW) {
@@ -308,11 +365,34 @@ __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a)
   if (nsteps <= 0) return;
   const int pre = nsteps < NSTAGE - 1 ? nsteps : NSTAGE - 1;
   for (int s = 0; s < pre; ++s) issue_stage(ps + s * PK, s);
+  // XF: a thread rewrites, in place, the x chunks its own LDS-DMA instructions brought (conv_igemm.h, XF): after its
+  // own counted vmcnt, before the barrier that publishes the stage
+  auto xform = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i)
+      if ((okbits >> (slot * NLX + i)) & 1u) {
+        bf16_t* p = reinterpret_cast<bf16_t*>(smem + slot * STAGE + TILE_Y + i * (NT * 16) + tid * 16);
+        Vec16<bf16_t> v;
+        v.load(p);
+        xf_apply<bf16_t>(v, xcs[i], xct[i], a.x_relu);
+        v.store(p);
+      }
+  };
+  if constexpr (XF) {
+    if (pre == 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    xform(0);
+  }
 
   // transposed-read byte offsets (row 4g+q and 16+4g+q), independent of the K-step
   const int r_lo = 4 * g + q, r_hi = 16 + 4 * g + q;
   for (int s = 0; s < nsteps; ++s) {
-    if (nsteps - 1 - s >= 1) {
+    if constexpr (XF) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // stage s was retired and transformed at the end of the previous step
+    } else if (nsteps - 1 - s >= 1) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -340,6 +420,16 @@ __global__ __launch_bounds__(64 * NWM * NWN) void wgrad_ring_kernel(WgradArgs a)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if constexpr (XF) {
+      if (s + 1 < nsteps) {  // behind this step's MFMAs: retire stage s+1 (stage s+2 may stay in flight), transform it
+        if (nsteps - 2 - s >= 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        xform((s + 1) % NSTAGE);
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -378,10 +468,14 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   const int ny8 = (ny + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
+  if (a.xs)
+    hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
+  else
+    hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -407,8 +501,12 @@ struct WgradPatchArgs {
   int tilesX, tilesY;
   int nCoB, nCiB;
   long long npatch, per_split;
+  const float* xs;  // XF (see WgradArgs)
+  const float* xt;
+  int x_relu;
 };
 
+template <bool XF>
 __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a) {
   constexpr int TH = 8, HW = 24, RB = 128;            // patch rows, halo slots per row, bytes per pixel row (64 ch)
   constexpr int YB = TH * 16 * RB;                    // dY tile bytes (16 KB)
@@ -477,6 +575,17 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
     }
   }
 
+  // XF: every halo chunk this lane stages carries the same 8 input channels (the swizzle depends on the lane alone)
+  float xcs[8], xct[8];
+  if constexpr (XF) {
+    const int sc = dch ^ (((drow >> 1) & 3) << 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xcs[e] = a.xs[ci0 + sc * 8 + e];
+      xct[e] = a.xt[ci0 + sc * 8 + e];
+    }
+  }
+
   for (long long pt = p_begin; pt < p_end; ++pt) {
     const int n = (int)(pt / tpi);
     const int rem = (int)(pt - (long long)n * tpi);
@@ -523,6 +632,25 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (XF) {
+      // normalise (+ activate) this lane's own halo chunks in place; padding (zero page) stays zero
+#pragma unroll
+      for (int i = 0; i < NDI; ++i) {
+        const int qi = widu + 6 * i;
+        if (qi >= NIY && qi < NIY + NIH) {
+          const int hp = (qi - NIY) * 8 + drow;
+          const int hy = hp / HW, hx = hp - hy * HW;
+          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+          if (hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+            bf16_t* p = reinterpret_cast<bf16_t*>(hbuf + (qi - NIY) * 1024 + lane * 16);
+            Vec16<bf16_t> v;
+            v.load(p);
+            xf_apply<bf16_t>(v, xcs, xct, a.x_relu);
+            v.store(p);
+          }
+        }
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < TH / 2; ++s) {
@@ -586,6 +714,7 @@ static bool wgrad_patch_applies(const WgradArgs& a) {
 static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
   WgradPatchArgs a;
   a.x = w.x; a.dy = w.dy; a.dw = w.dw;
+  a.xs = w.xs; a.xt = w.xt; a.x_relu = w.x_relu;
   a.N = w.N; a.H = w.OH; a.W = w.OW; a.Cin = w.Cin; a.Cout = w.Cout;
   a.tilesX = (w.OW + 15) / 16;
   a.tilesY = (w.OH + 7) / 8;
@@ -602,10 +731,14 @@ static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
   constexpr int lds = 8 * 16 * 128 + 10 * 24 * 128;  // 16 KB + 30 KB
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(wgrad3x3_patch_kernel, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
+  if (a.xs)
+    hipLaunchKernelGGL(wgrad3x3_patch_kernel<true>, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
+  else
+    hipLaunchKernelGGL(wgrad3x3_patch_kernel<false>, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -645,10 +778,14 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
   const int ny = (a.M + a.pix_per_split - 1) / a.pix_per_split;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
+  if (a.xs)
+    hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, true>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, false>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -667,7 +804,13 @@ extern "C" int maai_conv2d_wgrad(const maai_conv_desc* d, const void* x, const v
 
 extern "C" int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype,
                                        int target_blocks, void* stream) {
+  return maai_conv2d_wgrad_xf(d, x, dy, dw, dtype, target_blocks, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int maai_conv2d_wgrad_xf(const maai_conv_desc* d, const void* x, const void* dy, float* dw, int dtype,
+                                    int target_blocks, const float* xs, const float* xt, int x_relu, void* stream) {
   MAAI_CHECK_ARG(d && x && dy && dw, "conv2d_wgrad: null pointer");
+  MAAI_CHECK_ARG((xs == nullptr) == (xt == nullptr), "conv2d_wgrad: xs and xt come together");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_wgrad: dtype must be MAAI_BF16 or MAAI_F32");
   MAAI_CHECK_ARG(d->Cin % 32 == 0, "conv2d_wgrad: Cin must be a multiple of 32");
   MAAI_CHECK_ARG(d->Cout % 64 == 0, "conv2d_wgrad: Cout must be a multiple of 64");
@@ -680,6 +823,7 @@ extern "C" int maai_conv2d_wgrad_tuned(const maai_conv_desc* d, const void* x, c
   a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
   a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.OH = d->OH; a.OW = d->OW;
   a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
+  a.xs = xs; a.xt = xt; a.x_relu = x_relu;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY")) {
     if (wgrad_patch_applies(a)) return launch_wgrad_patch(a, st, target_blocks > 0 ? target_blocks / 3 : 0);

@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):
 class ConvEpilogue(C.Structure):
     """maai_conv_epilogue"""
     _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p), ("mask_bits", c_i), ("sum_increment", c_i),
-                ("a2", c_p), ("ak1", c_p), ("ak2", c_p), ("ak3", c_p), ("a_out", c_p)]
+                ("a2", c_p), ("ak1", c_p), ("ak2", c_p), ("ak3", c_p), ("a_out", c_p),
+                ("xs", c_p), ("xt", c_p), ("x_relu", c_i), ("xb", c_p), ("xs2", c_p), ("xt2", c_p), ("x_out", c_p), ("x_bits", c_p)]
 
 
 EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY, EPI_DGRAD_REDUCE = range(6)
@@ -47,6 +48,7 @@ SIGNATURES = {
     "maai_conv2d_igemm_fused": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, _P_EPI, c_i, c_p]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maai_conv2d_wgrad_xf": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
     "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),
     "maai_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
@@ -86,19 +88,37 @@ class MaaiError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
+
+
+def _autobuild():
+    """Build the library when only the sources travelled.  Every rank of a torchrun launch gets here at once, so
+    the build runs under an exclusive file lock and build.py links to a temporary file that it renames into place:
+    the ranks that lose the race wait, then find a complete library."""
+    import fcntl
+    import importlib.util
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(LIB_PATH):
+                spec = importlib.util.spec_from_file_location("maai_build", os.path.join(PKG_ROOT, "build.py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                mod.build(verbose=False)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def lib():
     """Load (once) and return the shared library; raise loudly if it is absent."""
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH) and os.environ.get("MAAI_NO_AUTOBUILD", "0") != "1":
-            # the library is an in-tree build product: compile it (hipcc, ~10 s) rather than fail when only
+            # the library is an in-tree build product: compile it (hipcc) rather than fail when only
             # the sources travelled; there is still no non-HIP fallback.
             try:
-                import importlib.util
-                spec = importlib.util.spec_from_file_location("maai_build", os.path.join(PKG_ROOT, "build.py"))
-                mod = importlib.util.module_from_spec(spec)
-                spec.loader.exec_module(mod)
-                mod.build(verbose=False)
+                _autobuild()
             except Exception as e:  # noqa: BLE001
                 raise MaaiError("libmaai_hip.so is missing and could not be built: %s" % e)
         if not os.path.exists(LIB_PATH):
@@ -110,8 +130,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library drift
             fn.restype = res
             fn.argtypes = args
-        if handle.maai_abi_version() != 1:
-            raise MaaiError("libmaai_hip.so ABI version mismatch")
+        if handle.maai_abi_version() != ABI_VERSION:
+            raise MaaiError("libmaai_hip.so has ABI version %d, this package binds version %d: rebuild it "
+                            "(python multimodal-active-ai_amd/build.py --force)" % (handle.maai_abi_version(), ABI_VERSION))
         _LIB = handle
     return _LIB
 

@@ -249,10 +249,50 @@ def _check_conv(conv):
 
 _DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
 _EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0"}
+# Normalise-on-load (kernels.Lazy): a unit whose only consumers are convolutions of this library does not run its
+# BatchNorm/ReLU pass; it hands on its RAW convolution output with (scale, shift) and the consumers (forward
+# convolution, weight gradient) apply the transform to the operand they stage in LDS.  "lazy": inside a block
+# (conv1 -> conv2 -> conv3, and the stem -> layer1); "join": the residual join relu(bn3(y3) + shortcut) is formed by
+# the NEXT block's conv1, which hands the joined activation back once for the shortcut and the backward pass.
+# Bit-identical to the materialised path (tests/test_gpu_xf.py); MAAI_LAZY=0 / MAAI_JOIN=0 switch them off.
+_LAZY = {"enabled": os.environ.get("MAAI_LAZY", "1") != "0", "join": os.environ.get("MAAI_JOIN", "1") != "0"}
 
 
-def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None):
+def set_lazy(lazy=None, join=None):
+    if lazy is not None:
+        _LAZY["enabled"] = bool(lazy)
+    if join is not None:
+        _LAZY["join"] = bool(join)
+
+
+def materialise(x):
+    """The tensor a ``kernels.Lazy`` activation stands for (one BatchNorm pass); tensors pass through."""
+    if not isinstance(x, K.Lazy):
+        return x
+    if x.b is None:
+        return K.bn_act_fwd(x.y, x.scale, x.shift, None, x.relu)
+    if x.scale2 is None:
+        return K.bn_act_fwd(x.y, x.scale, x.shift, x.b, x.relu)
+    return K.bn_act_fwd2(x.y, x.scale, x.shift, x.b, x.scale2, x.shift2, x.relu)
+
+
+def _lazy_input_ok(x, conv, dtype):
+    """Can ``conv`` form the lazy activation ``x`` on load?  (a two-tensor join needs a pointwise stride-1 layer)"""
+    cin = conv.in_channels
+    if cin % (32 if dtype == torch.bfloat16 else 16) or cin > 4096:
+        return False
+    if x.b is not None:
+        return conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and cin <= 2048
+    return True
+
+
+def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None,
+             lazy_out=False, side=None):
     """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).
+    ``x`` may be a ``kernels.Lazy`` activation (formed on load).  If it is a two-tensor join, the joined activation
+    (and, bf16 with gradients, its 1-bit ReLU mask) comes back in ``side["joined"]`` / ``side["bits"]``.
+    ``lazy_out``: do not run this unit's BatchNorm pass — return a ``kernels.Lazy`` (rec.out stays None until the
+    consumer of a join patches it in).
     ``defer``: stop after the statistics — returns ((y, scale, shift), rec) with rec.out = None, for a shortcut
     branch whose normalisation is applied by the unit it is added to; ``branch`` = such a (y2, scale2, shift2)
     triple, applied and added in this unit's single BN pass (maai_bn_act_fwd2) in place of ``residual``.
@@ -267,10 +307,29 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
     fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
+    eval_fused = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
+                  and wq.shape[0] % 64 == 0)
+    if isinstance(x, K.Lazy) and (fused or eval_fused or form != "fwd" or not _lazy_input_ok(x, conv, dtype)):
+        x = materialise(x)
+        if side is not None:
+            side["joined"] = x
+    join_bits = bool(keep and x.dtype == torch.bfloat16 and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"])
+
+    def conv_x(stats):
+        """the convolution of this unit; a two-tensor lazy input is joined on load and handed back through ``side``"""
+        if isinstance(x, K.Lazy) and x.b is not None:
+            res = K.conv2d(x, wq, stride, pad, pad_w, stats=stats, join_out=True, join_bits=join_bits)
+            nret = 2 if stats else 1
+            if side is None:
+                raise MaaiError("unit_fwd: a joined input needs ``side`` to hand the activation back")
+            side["joined"] = res[nret]
+            side["bits"] = res[nret + 1] if join_bits else None
+            return (res[0], res[1]) if stats else res[0]
+        return K.conv2d(x, wq, stride, pad, pad_w, stats=stats)
     y = None
     if given is not None:
         training = given.training
-        y = K.conv2d(x, wq, stride, pad, pad_w)
+        y = conv_x(False)
         mean, invstd, scale, shift, count, world = given.mean, given.invstd, given.scale, given.shift, given.count, given.world
     elif training:
         if fused:
@@ -278,7 +337,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
             c = wq.shape[0]
             count = x.numel() // x.shape[-1]
         else:
-            y, part = K.conv2d(x, wq, stride, pad, pad_w, stats=True)
+            y, part = conv_x(True)
             c = y.shape[-1]
             count = y.numel() // c
         sums = K.reduce_partials(part)
@@ -298,14 +357,15 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
         mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
         scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-        if not keep and not defer and branch is None and _EVAL_FUSE["enabled"] and wq.shape[0] % 64 == 0:
+        if eval_fused:
             # inference with frozen statistics: normalise (+ shortcut) + activate in the convolution's own epilogue,
             # one launch per unit and no raw conv output in HBM (MAAI_EPI_BN_ACT on any kernel size)
             return K.conv2d_bn_act(x, wq, scale, shift, residual, relu, stride, pad, pad_w), None
         if not fused:
-            y = K.conv2d(x, wq, stride, pad, pad_w)
+            y = conv_x(False)
         mean = invstd = None
         count, world = x.numel() // x.shape[-1] if fused else y.numel() // y.shape[-1], 1
+    xb = side["joined"] if (side is not None and isinstance(x, K.Lazy) and x.b is not None) else x  # what the backward reads
     if fused:
         out = K.conv2d_bn_act(x, wq, scale, shift, residual, relu)
         if not keep:
@@ -325,6 +385,21 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
         if relu or residual is not None or branch is not None:
             raise MaaiError("unit_fwd: a deferred unit is a plain conv + BN shortcut branch")
         out = None
+    elif lazy_out:
+        # no BatchNorm pass here: the consumer convolutions form the activation on load
+        if branch is not None:
+            lz = K.Lazy(y, scale, shift, relu, branch[0], branch[1], branch[2])
+        else:
+            lz = K.Lazy(y, scale, shift, relu, residual)
+        if not keep:
+            return lz, None
+        r = _Rec()
+        r.x, r.y, r.out, r.conv, r.bn = xb, y, None, conv, bn
+        r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
+        r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
+        r.in_hw = (x.shape[1], x.shape[2])
+        r.fused, r.shift, r.bits = False, shift, None
+        return lz, r
     elif branch is not None:
         if residual is not None:
             raise MaaiError("unit_fwd: residual and branch are exclusive")
@@ -338,7 +413,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
     if not keep:
         return ((y, scale, shift) if defer else out), None
     r = _Rec()
-    r.x, r.y, r.out, r.conv, r.bn = x, y, out, conv, bn
+    r.x, r.y, r.out, r.conv, r.bn = xb, y, out, conv, bn
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
@@ -399,11 +474,17 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
     incr = bool(sum_increment and accumulate)
     fuse = below is not None and _DGRAD_REDUCE["enabled"] and (not empty or incr) and below.y is not None
     from_y = False
+    relu_mask = materialise(relu_mask)
     if below is not None:
         if not below.relu:
             raise MaaiError("conv_dgrad: the unit below has no ReLU to take a mask from")
         from_y = fuse and not below.has_res
         relu_mask = None if from_y else below.out
+        if relu_mask is None and not from_y:
+            # a lazy unit never stored its activation: rebuild the mask tensor (only without the fused reduction)
+            if below.has_res:
+                raise MaaiError("conv_dgrad: the joined activation of the unit below was never handed back")
+            relu_mask = K.bn_act_fwd(below.y, below.scale, below.shift, None, True)
     use_bits = fuse and below.has_res and getattr(below, "bits", None) is not None
     if use_bits:
         relu_mask = below.bits

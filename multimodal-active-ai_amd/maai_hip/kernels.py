@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from ._lib import (BF16, EPI_BN_ACT, EPI_BWD_APPLY, EPI_BWD_REDUCE, EPI_DGRAD_REDUCE, EPI_STATS_ONLY, F32, ConvDesc, ConvEpilogue, MaaiError,
+from ._lib import (BF16, EPI_BN_ACT, EPI_BWD_APPLY, EPI_BWD_REDUCE, EPI_DGRAD_REDUCE, EPI_STATS_ONLY, EPI_STORE, F32, ConvDesc, ConvEpilogue, MaaiError,
                    check, lib)
 
 
@@ -108,9 +108,55 @@ def make_desc(x, w, stride, pad_h, pad_w, grid_hw=None, out_hw=None, out_stride=
                     1 if accumulate else 0)
 
 
+class Lazy(object):
+    """An activation that exists only as the raw convolution output it is computed from: act(y*scale + shift), or
+    the join act((y*scale + shift) + r(b*scale2 + shift2)) of two raw tensors (b added as is when scale2 is None).
+    Consumers (conv2d / conv2d_wgrad with ``xf=``) form it on load (maai_conv_epilogue.xs ...)."""
+    __slots__ = ("y", "scale", "shift", "relu", "b", "scale2", "shift2")
+
+    def __init__(self, y, scale, shift, relu=True, b=None, scale2=None, shift2=None):
+        self.y, self.scale, self.shift, self.relu, self.b, self.scale2, self.shift2 = y, scale, shift, relu, b, scale2, shift2
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    @property
+    def dtype(self):
+        return self.y.dtype
+
+
+def _xf_epilogue(xf, join_out=None, join_bits=None):
+    _gpu(xf.y, xf.scale, xf.shift, xf.b, xf.scale2, xf.shift2, join_out, join_bits)
+    c = xf.y.shape[-1]
+    for t in (xf.scale, xf.shift, xf.scale2, xf.shift2):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != c):
+            raise MaaiError("normalise-on-load: per-channel coefficients must be fp32 [Cin]")
+    if xf.b is not None and (xf.b.shape != xf.y.shape or xf.b.dtype != xf.y.dtype):
+        raise MaaiError("normalise-on-load: the second tensor must match the first")
+    if (xf.scale2 is None) != (xf.shift2 is None) or (xf.b is None and (xf.scale2 is not None or join_out is not None)):
+        raise MaaiError("normalise-on-load: scale2/shift2/out belong to the two-tensor join")
+    epi = ConvEpilogue(EPI_STORE, 0, None, None, None, None)
+    epi.xs, epi.xt, epi.x_relu = xf.scale.data_ptr(), xf.shift.data_ptr(), 1 if xf.relu else 0
+    if xf.b is not None:
+        epi.xb = xf.b.data_ptr()
+        if xf.scale2 is not None:
+            epi.xs2, epi.xt2 = xf.scale2.data_ptr(), xf.shift2.data_ptr()
+        if join_out is not None:
+            epi.x_out = join_out.data_ptr()
+        if join_bits is not None:
+            epi.x_bits = join_bits.data_ptr()
+    return epi
+
+
 def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None, out_hw=None, out_stride=1,
-           out_off=(0, 0), accumulate=False, relu_mask=None):
-    """y = conv(x, w) (NHWC / KHWC), optionally y *= (relu_mask > 0).  Returns y or (y, stats_partial[rows,2,Cout])."""
+           out_off=(0, 0), accumulate=False, relu_mask=None, join_out=False, join_bits=False):
+    """y = conv(x, w) (NHWC / KHWC), optionally y *= (relu_mask > 0).  Returns y or (y, stats_partial[rows,2,Cout]).
+    ``x`` may be a ``Lazy`` activation: it is then formed on load from its raw tensor(s) and never stored — except
+    that a two-tensor join is handed back once when ``join_out`` (and its 1-bit ReLU mask when ``join_bits``):
+    the return value then ends with (joined [, bits])."""
+    if isinstance(x, Lazy):
+        return _conv2d_lazy(x, w, stride, pad_h, pad_w, stats, join_out, join_bits)
     _gpu(x, w, out, relu_mask)
     if x.dtype != w.dtype:
         raise MaaiError("conv2d: x and w must share the storage dtype")
@@ -133,6 +179,35 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
         check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), _dt(x), _stream()),
               "maai_conv2d_igemm")
     return (out, part) if stats else out
+
+
+def _conv2d_lazy(xf, w, stride, pad_h, pad_w, stats, join_out, join_bits):
+    x = xf.y
+    _gpu(x, w)
+    if x.dtype != w.dtype:
+        raise MaaiError("conv2d: x and w must share the storage dtype")
+    d = make_desc(x, w, stride, pad_h, pad_w)
+    out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
+    jo = torch.empty_like(x) if (join_out and xf.b is not None) else None
+    jb = torch.empty((x.numel() // 8,), dtype=torch.uint8, device=x.device) if (jo is not None and join_bits and x.dtype == torch.bfloat16) else None
+    epi = _xf_epilogue(xf, jo, jb)
+    part = None
+    if stats:
+        rows = lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(x))
+        part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=x.device)
+    m = d.N * d.OHg * d.OWg
+    es = x.element_size()
+    nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[xf%d] M%d Cin%d Cout%d k%dx%d s%d os1 acc0" % (2 if xf.b is not None else 1, m, d.Cin, d.Cout, d.KH, d.KW, d.stride)
+    nbytes = es * (x.numel() * (1 + (1 if xf.b is not None else 0) + (1 if jo is not None else 0)) + w.numel() + m * d.Cout) + (0 if jb is None else jb.numel())
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes):
+        check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), None, C.byref(epi), _dt(x), _stream()),
+              "maai_conv2d_igemm_fused")
+    ret = (out, part) if stats else (out,)
+    if join_out:
+        ret = ret + (jo,)
+        if join_bits:
+            ret = ret + (jb,)
+    return ret if len(ret) > 1 else ret[0]
 
 
 def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), axf=False):
@@ -271,7 +346,15 @@ def _wgrad_target(d, x, dy, dtype_code):
 
 
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
-    """dw[Cout,KH,KW,Cin] fp32 for y = conv(x, w); dy dense [N,OH,OW,Cout]."""
+    """dw[Cout,KH,KW,Cin] fp32 for y = conv(x, w); dy dense [N,OH,OW,Cout].  ``x`` may be a single-tensor ``Lazy``
+    activation (normalised on load)."""
+    xs = xt = None
+    x_relu = 0
+    if isinstance(x, Lazy):
+        if x.b is not None:
+            raise MaaiError("conv2d_wgrad: a two-tensor join must be materialised by its consumer convolution")
+        _gpu(x.scale, x.shift)
+        xs, xt, x_relu, x = x.scale, x.shift, 1 if x.relu else 0, x.y
     _gpu(x, dy)
     n, ih, iw, cin = x.shape
     _, oh, ow, cout = dy.shape
@@ -280,7 +363,8 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
     dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     nm = "conv_wgrad" if not DETAIL[0] else "conv_wgrad M%d Cin%d Cout%d k%dx%d s%d" % (dy.numel() // cout, cin, cout, kh, kw, stride)
     with _timed(nm, 2.0 * dy.numel() * kh * kw * cin * FLOPS_SCALE[0], x.element_size() * (x.numel() + dy.numel()) + 4 * dw.numel()):
-        check(lib().maai_conv2d_wgrad_tuned(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), target, _stream()), "maai_conv2d_wgrad_tuned")
+        check(lib().maai_conv2d_wgrad_xf(C.byref(d), _p(x), _p(dy), _p(dw), _dt(x), target, _p(xs), _p(xt), x_relu, _stream()),
+              "maai_conv2d_wgrad_xf")
     return dw
 
 

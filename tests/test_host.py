@@ -44,7 +44,18 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds exactly the header's functions
     assert sorted(_lib.SIGNATURES) == names
     lib = _lib.lib()
-    assert lib.maai_abi_version() == 1
+    text = open(os.path.join(ROOT, "include", "maai_hip.h")).read()
+    header_version = int(re.search(r"#define MAAI_ABI_VERSION (\d+)", text).group(1))
+    assert lib.maai_abi_version() == header_version == _lib.ABI_VERSION
+
+
+def test_conv_epilogue_matches_header_struct():
+    from maai_hip._lib import ConvEpilogue
+    text = open(os.path.join(ROOT, "include", "maai_hip.h")).read()
+    body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} maai_conv_epilogue;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [re.sub(r"^.*[\s\*]", "", part.strip()) for part in body.split(";") if part.strip()]
+    assert names == [n for n, _ in ConvEpilogue._fields_]
 
 
 def test_conv_desc_matches_header_struct():
