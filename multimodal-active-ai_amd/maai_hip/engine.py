@@ -276,6 +276,15 @@ def materialise(x):
     return K.bn_act_fwd2(x.y, x.scale, x.shift, x.b, x.scale2, x.shift2, x.relu)
 
 
+def unit_output(rec):
+    """The activation a unit's record stands for (a lazy unit never stored it: one BatchNorm pass rebuilds it)."""
+    if rec.out is not None:
+        return rec.out
+    if rec.has_res:
+        raise MaaiError("unit_output: the join of this unit has not been formed yet")
+    return K.bn_act_fwd(rec.y, rec.scale, rec.shift, None, rec.relu)
+
+
 def _lazy_input_ok(x, conv, dtype):
     """Can ``conv`` form the lazy activation ``x`` on load?  (a two-tensor join needs a pointwise stride-1 layer)"""
     cin = conv.in_channels
@@ -666,29 +675,51 @@ def _lighten(r):
     return r
 
 
-def _block_fwd(blk, xin, dtype, keep, given=None):
-    """One residual block (resnet.py:59-77 / :113-135).  Returns (out, (r1, r2, r3, rd))."""
+def _is_bottleneck(blk):
+    return hasattr(blk, "conv3")
+
+
+def _joins_on_load(blk, dtype):
+    """Can ``blk``'s first convolution form the previous block's residual join on load?"""
+    c1 = blk.conv1
+    return (_LAZY["enabled"] and _LAZY["join"] and _is_bottleneck(blk) and c1.kernel_size == (1, 1) and c1.stride == (1, 1)
+            and c1.padding == (0, 0) and c1.in_channels <= 2048 and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0
+            and not _fusable(c1, "fwd"))
+
+
+def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False):
+    """One residual block (resnet.py:59-77 / :113-135).  ``xin``: a tensor or a ``kernels.Lazy`` activation (the stem's,
+    or the previous block's residual join).  ``lazy_out``: return the block output as a Lazy join for the next
+    block's conv1 to form.  Returns (out, (r1, r2, r3, rd), xin tensor or single-tensor Lazy as materialised here,
+    1-bit mask of xin or None)."""
     g1, g2, g3, gd = given if given is not None else (None, None, None, None)
-    if hasattr(blk, "conv3"):  # Bottleneck
-        o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1)
-        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2)
+    lazy = _LAZY["enabled"]
+    side = {}
+    needs_identity = blk.downsample is None
+    if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or (xin.b is not None and not _joins_on_load(blk, dtype))):
+        xin = materialise(xin)   # the identity shortcut reads it / conv1 cannot join it
+    o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=lazy, side=side)
+    xin_bits = side.get("bits")
+    if isinstance(xin, K.Lazy) and xin.b is not None:
+        xin = side["joined"]     # conv1 formed the join and handed it back
+    if _is_bottleneck(blk):
+        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=lazy)
         last_conv, last_bn = blk.conv3, blk.bn3
     else:  # BasicBlock
-        o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1)
         r2 = None
         last_conv, last_bn = blk.conv2, blk.bn2
     rd = None
     if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
         # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored
         br, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True, given=gd)
-        out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br, given=g3)
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br, given=g3, lazy_out=lazy_out)
     else:
         if blk.downsample is not None:
             idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, given=gd)
         else:
             idn = xin
-        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep, given=g3)
-    return out, (r1, r2, r3, rd)
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep, given=g3, lazy_out=lazy_out)
+    return out, (r1, r2, r3, rd), xin, xin_bits
 
 
 def backbone_fwd(resnet, x, dtype, keep):
@@ -696,16 +727,25 @@ def backbone_fwd(resnet, x, dtype, keep):
     xs, wq, form = stem_input(x, resnet.conv1, dtype)
     tape = []
     cin = resnet.conv1.weight.shape[1]
+    blocks = list(_blocks(resnet))
+    # the stem's activation is formed on load by layer1's first convolutions when that block has a projection
+    # shortcut (an identity shortcut would read the tensor itself)
+    stem_lazy = (_LAZY["enabled"] and bool(blocks) and blocks[0].downsample is not None and not _fusable(blocks[0].conv1, "fwd")
+                 and not _fusable(blocks[0].downsample[0], "fwd"))
     K.FLOPS_SCALE[0] = (49.0 * cin) / (wq.shape[1] * wq.shape[2] * wq.shape[3])  # executed K includes zero padding
-    out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form)
+    out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form, lazy_out=stem_lazy)
     K.FLOPS_SCALE[0] = 1.0
     tape.append(("stem", r))
     ckpt = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
-    for blk in _blocks(resnet):
-        xin = out
-        out, recs = _block_fwd(blk, xin, dtype, keep)
+    prev3 = None   # record of the previous block's last unit while its output is still a Lazy join
+    for i, blk in enumerate(blocks):
+        lazy_out = i + 1 < len(blocks) and _joins_on_load(blocks[i + 1], dtype) and _FUSE["max_cin"] == 0
+        out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out)
+        if prev3 is not None:
+            prev3.out, prev3.bits = xin, xin_bits   # the join this block's conv1 formed IS the previous block's output
+        prev3 = recs[2] if (lazy_out and keep) else None
         if ckpt:
-            tape.append(("ckpt", blk, xin, tuple(_lighten(r) for r in recs), out))
+            tape.append(("ckpt", blk, xin, tuple(_lighten(r) for r in recs), out if not isinstance(out, K.Lazy) else None))
         else:
             tape.append(("block",) + recs)
     return out, tape
@@ -745,7 +785,8 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
             if sp is None and (sa is not None or sb is not None):
                 raise MaaiError("block_bwd: the two passes of a strided shortcut must both reduce or both not")
         else:
-            dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x, presums=s)
+            # (a stride-1 shortcut's pass rewrites — and masks — every pixel: the first pass then needs no mask)
+            dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x if strided else None, presums=s)
             if prev is not None:
                 dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
             else:
@@ -776,7 +817,7 @@ def backbone_bwd(tape, dout, grads, dtype):
             # rebuild this block's records from its input and the saved statistics, differentiate, drop them; the
             # block below is not materialised yet, so its BN-backward sums cannot ride this block's last epilogue
             _, blk, xin, lights, _ = entry
-            _, recs = _block_fwd(blk, xin, dtype, True, given=lights)
+            _, recs, _, _ = _block_fwd(blk, xin, dtype, True, given=lights)
             dout, sums = block_bwd(("block",) + recs, dout, grads, dtype, prev=None, presums=sums)
             tape[i] = None
             del recs

@@ -213,12 +213,12 @@ def test_every_block_teacher_forced(mods, arch, cm, shape, prec, fuse):
     gcos = 0.995 if prec == "bf16" else 0.999
     # stem
     stem_ref = O.stem_forward(sd, x, True, storage)
-    got = _nchw(tape[0][1].out)
+    got = _nchw(engine.unit_output(tape[0][1]))
     assert (got - stem_ref).abs().max() <= ftol * stem_ref.abs().max()
     g = torch.Generator().manual_seed(3)
     for entry, blk in zip(tape[1:], O.block_plan(arch)):
         _, r1, r2, r3, rd = entry
-        x_in = _nchw(r1.x)
+        x_in = _nchw(engine.materialise(r1.x))
         keys = [k for k in sd if k.startswith(blk["prefix"] + ".") and k.endswith((".weight", ".bias"))]
         leaf = {k: sd[k].clone().requires_grad_(True) for k in keys}
         work = dict(sd)
@@ -382,6 +382,83 @@ def test_backward_fusions_are_bit_identical(mods, prec):
         #  DESIGN.md "conditioning"; the per-block test above is the tight one)
         assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, n
         assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), n
+
+
+def _tape_bytes(engine, tape):
+    seen = {}
+
+    def note(t):
+        if torch.is_tensor(t):
+            seen[t.untyped_storage().data_ptr()] = t.untyped_storage().nbytes()
+
+    def walk(o):
+        if isinstance(o, (tuple, list)):
+            for q in o:
+                walk(q)
+        elif isinstance(o, engine._Rec):
+            for f in ("x", "y", "out", "bits"):
+                v = getattr(o, f, None)
+                if hasattr(v, "y") and not torch.is_tensor(v):   # kernels.Lazy
+                    note(v.y)
+                    note(v.b)
+                else:
+                    note(v)
+        else:
+            note(o)
+    walk(tape)
+    return sum(seen.values())
+
+
+@pytest.mark.parametrize("arch,cm,shape", [("resnet50", 1, (4, 3, 32, 32)), ("resnet50", 4, (4, 12, 30, 30)), ("resnet18", 1, (4, 3, 32, 32))])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
+    """BatchNorm+ReLU formed on load inside the blocks (MAAI_LAZY) and the residual join formed by the next block's
+    conv1 (MAAI_JOIN) against the materialised passes they replace (resnet.py:101-133): same feature map and BatchNorm
+    buffers bit for bit, same gradients up to the order of the fp32 atomic adds / BN sums, fewer bytes held for
+    the backward pass, and the same again under block recompute."""
+    from maai_hip import engine
+    engine.set_precision(prec)
+    dtype = engine.compute_dtype()
+    head_in = (512 if arch == "resnet18" else 2048) * 16
+    x = _u8(5, shape).float().cuda()
+    res = {}
+    try:
+        for tag, (lazy, join, rec) in (("plain", (False, False, False)), ("lazy", (True, False, False)), ("join", (True, True, False)),
+                                       ("join+recompute", (True, True, True))):
+            engine.set_lazy(lazy, join)
+            engine.set_recompute(rec)
+            m = _build(mods, arch, cm, head_in, shape[0], shape[2:], 0.5)
+            m.train()
+            with torch.no_grad():
+                feat, tape = engine.backbone_fwd(m.f, x, dtype, keep=True)
+            torch.cuda.synchronize()
+            held = _tape_bytes(engine, tape)
+            g = torch.Generator().manual_seed(9)
+            dout = torch.randn(feat.shape, generator=g).to(dtype).cuda()
+            grads = {}
+            engine.backbone_bwd(tape, dout, grads, dtype)
+            torch.cuda.synchronize()
+            named = {n: grads[id(p)].float().cpu() for n, p in m.f.named_parameters() if id(p) in grads}
+            bufs = {n: b.clone().cpu() for n, b in m.f.named_buffers()}
+            with torch.no_grad():
+                feat_ng, _ = engine.backbone_fwd(m.f, x, dtype, keep=False)   # the no-grad view of the SimCLR step
+            res[tag] = (feat.float().cpu(), named, held, bufs, feat_ng.float().cpu())
+    finally:
+        engine.set_lazy(True, True)
+        engine.set_recompute(False)
+    for tag in ("lazy", "join", "join+recompute"):
+        assert torch.equal(res[tag][0], res["plain"][0]), tag
+        assert torch.equal(res[tag][4], res["plain"][4]), tag
+        for n, b in res["plain"][3].items():
+            assert torch.equal(res[tag][3][n], b), (tag, n)
+        assert res[tag][1].keys() == res["plain"][1].keys() and len(res["plain"][1]) > 50
+        for n, gp in res["plain"][1].items():
+            gf = res[tag][1][n]
+            scale = gp.abs().max().item() + 1e-30
+            assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, (tag, n)
+            assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), (tag, n)
+    assert res["lazy"][2] < 0.9 * res["plain"][2], (res["lazy"][2], res["plain"][2])
+    assert res["join"][2] <= res["lazy"][2]
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
