@@ -8,11 +8,20 @@ One step = one pass of the hot path over one per-GPU batch of synthetic source
 images already resident in HBM (reference --num-fixations 1
 semantics, Contrastive_Learning.py:638-700): two-view HIP augmentation ->
 view-1 forward (no grad, train-mode BN) -> view-2 forward -> NT-Xent (h1
-detached; embedding all-gather when N > 1) -> backward -> (gradient all-reduce
-when N > 1) -> Adam.  Workload at every N: BASELINE configs[1] per GPU —
-ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224, per-GPU
-batch 256, bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,
-1024,128), temperature 0.5 — i.e. weak scaling.  Prints ONE JSON line on rank 0.
+detached; embedding all-gather when N > 1, view 1's started under the view-2
+forward) -> backward (gradient buckets all-reduced on a side stream as the
+backward produces them when N > 1) -> Adam.
+Workload: ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224,
+bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,1024,128),
+temperature 0.5.  N = 1, 2, 4: BASELINE configs[1] per GPU (per-GPU batch 256,
+weak scaling).  N = 8: BASELINE configs[2] = the metric's own configuration,
+per-GPU batch 512 (global 4096) with block recompute (512 images of stored
+activations do not fit 288 GB); --batch / --recompute override.
+Synthetic images are per-image random low-frequency colour patterns plus
+noise, generated on the device, so that the two views of one image correlate
+and the contrastive loss is NOT the 2*ln(2N-1) of collapsed embeddings; the
+run fails if the loss is not finite or does not move over the timed steps.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -33,7 +42,20 @@ for d in (ROOT, PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"))
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): dense bf16 MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r01_pmc_traffic_b256_v5.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+PMC_SUMMARY = "r02_pmc_traffic_b256.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/profile_round.sh)
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fn.encode())
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -41,18 +63,24 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE cfg2: 256)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 256 = BASELINE cfg2; 512 at --gpus 8 = cfg3, global 4096)")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--temperature", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps (after one untimed warm-up step); the median is reported")
     ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
     ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
     ap.add_argument("--recompute", action="store_true",
                     help="block recompute in the backward (fits --batch 512 = global 4096 on 8 GPUs in 288 GB; one extra forward)")
-    return ap.parse_args()
+    ap.add_argument("--no-recompute", action="store_true")
+    args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 512 if args.gpus >= 8 else 256
+        if args.gpus >= 8 and not args.no_recompute:
+            args.recompute = True
+    return args
 
 
 def build(args, device, world):
@@ -74,12 +102,36 @@ def build(args, device, world):
     return model, Model_Util.get_optimizer(model, A)
 
 
+def synthetic_images(b, size, device, seed):
+    """[b, size, size, 3] u8, generated on the device: per image a sum of three random low-frequency plane waves per
+    colour channel (random orientation, wavelength 1/1 .. 1/6 of the image, phase, amplitude) around a random mean
+    colour, plus +-12 levels of per-pixel noise.  Two random crops of ONE image share its colours and orientation
+    statistics; two different images do not — unlike uniform noise, for which every embedding is the same."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    ys, xs = torch.meshgrid(torch.arange(size, device=device, dtype=torch.float32),
+                            torch.arange(size, device=device, dtype=torch.float32), indexing="ij")
+    out = torch.empty((b, size, size, 3), dtype=torch.uint8, device=device)
+    chunk = 32
+    for b0 in range(0, b, chunk):
+        n = min(chunk, b - b0)
+        img = 40.0 + 175.0 * torch.rand((n, 1, 1, 3), device=device, generator=gen)
+        for _ in range(3):
+            theta = 3.14159265 * torch.rand((n, 1, 1, 1), device=device, generator=gen)
+            freq = 6.2831853 * (1.0 + 5.0 * torch.rand((n, 1, 1, 1), device=device, generator=gen)) / size
+            phase = 6.2831853 * torch.rand((n, 1, 1, 3), device=device, generator=gen)
+            amp = 50.0 * torch.rand((n, 1, 1, 3), device=device, generator=gen)
+            arg = freq * (torch.cos(theta) * xs[None, :, :, None] + torch.sin(theta) * ys[None, :, :, None])
+            img = img + amp * torch.sin(arg + phase)
+        img = img + 24.0 * (torch.rand((n, size, size, 3), device=device, generator=gen) - 0.5)
+        out[b0:b0 + n] = img.clamp_(0.0, 255.0).to(torch.uint8)
+    return out
+
+
 def make_step(args, model, opt, device, rank, world):
     import Objective
     from maai_hip import kernels as K
     from maai_hip.dist import GradAllReduce
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
-    images = torch.randint(0, 256, (args.batch, args.img, args.img, 3), dtype=torch.uint8, device=device, generator=gen)
+    images = synthetic_images(args.batch, args.img, device, 1234 + rank)
     sync = GradAllReduce(list(model.parameters())) if world > 1 else None
     state = {"it": 0}
 
@@ -105,7 +157,9 @@ def make_step(args, model, opt, device, rank, world):
 
 
 def cpu_baseline(args):
-    """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload."""
+    """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload: one untimed warm-up step,
+    then ``--cpu-steps`` timed steps of ``--cpu-batch`` images; the median step time is reported."""
+    import statistics
     from oracle import simclr_oracle as O
     try:
         ncpu = len(os.sched_getaffinity(0))
@@ -115,20 +169,24 @@ def cpu_baseline(args):
     b = args.cpu_batch
     exp = O.expansion(args.arch)
     sd = O.pattern_state_dict(args.arch, 1, 512 * exp * 16)
-    g = torch.Generator().manual_seed(0)
-    x1 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
-    x2 = torch.randint(0, 256, (b, 3, args.img, args.img), generator=g).float()
+    imgs = synthetic_images(2 * b, args.img, torch.device("cpu"), 99).permute(0, 3, 1, 2).float().contiguous()
+    x1, x2 = imgs[:b], imgs[b:]
     opt = {}
-    sys.stderr.write("[bench] cpu baseline: %d threads, batch %d ...\n" % (torch.get_num_threads(), b))
+    sys.stderr.write("[bench] cpu baseline: %d threads, batch %d, 1 warm-up + %d timed steps ...\n" % (torch.get_num_threads(), b, args.cpu_steps))
     sys.stderr.flush()
-    t0 = time.time()
-    for i in range(args.cpu_steps):
+    times = []
+    for i in range(args.cpu_steps + 1):
+        t0 = time.time()
         O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)
-        sys.stderr.write("[bench] cpu baseline step %d done at %.1f s\n" % (i, time.time() - t0))
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        sys.stderr.write("[bench] cpu baseline step %d: %.1f s%s\n" % (i, dt, " (warm-up, not counted)" if i == 0 else ""))
         sys.stderr.flush()
-    dt = (time.time() - t0) / args.cpu_steps
-    return dict(value=round(b / dt, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%s 3x%dx%d, batch %d, %d steps (fp32, torch-CPU oracle)" % (args.arch, args.img, args.img, b, args.cpu_steps))
+    med = statistics.median(times)
+    return dict(value=round(b / med, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample="%s 3x%dx%d, batch %d, median of %d steps after 1 warm-up step (fp32, torch-CPU oracle); step times %s s"
+                       % (args.arch, args.img, args.img, b, args.cpu_steps, ["%.1f" % t for t in times]))
 
 
 def main():
@@ -166,11 +224,18 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    losses = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        losses.append(loss)   # device scalars: read after the timed region
     barrier()
     dt = time.perf_counter() - t0
+    losses = [float(v.item()) for v in losses]
+    if not all(v == v and abs(v) < 1e30 for v in losses):
+        raise SystemExit("bench.py: the loss is not finite over the timed steps: %s" % losses)
+    if len(losses) > 1 and max(losses) - min(losses) < 1e-6:
+        raise SystemExit("bench.py: the loss does not move over the timed steps (%s): the step is not training" % losses)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,11 +267,17 @@ def main():
         t = table[dom]
         sec = t["ms"] * 1e-3
         tf = t["flops"] / sec / 1e12
-        gbs = t["bytes"] / sec / 1e9
+        # roofline.achieved / frac use SURVEY §8(d)'s algorithmic bytes — every convolution reads its input once and
+        # writes its output once, nothing else — per launch, over the live HIP-event duration of the launch; the
+        # as-built figure (every tensor the launch's epilogue also reads or writes) is kept beside it
+        gbs = t["bytes_8d"] / sec / 1e9
+        gbs_built = t["bytes"] / sec / 1e9
         f_mfma, f_hbm = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
         common = dict(kernel=dom, traffic=None, launches=t["launches"], avg_launch_ms=round(t["ms"] / t["launches"], 4),
                       share_of_step=round(t["ms"] / ms, 3), frac_mfma=round(f_mfma, 4), frac_hbm=round(f_hbm, 4),
-                      achieved_TFLOPs=round(tf, 2), achieved_GBs=round(gbs, 1))
+                      achieved_TFLOPs=round(tf, 2), achieved_GBs=round(gbs, 1),
+                      algorithmic_GB_per_launch=round(t["bytes_8d"] / t["launches"] / 1e9, 3),
+                      as_built_GB_per_launch=round(t["bytes"] / t["launches"] / 1e9, 3), as_built_frac_hbm=round(gbs_built / PEAK_HBM_GBS, 4))
         if f_mfma >= f_hbm:
             roof = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(f_mfma, 4), **common)
         else:
@@ -217,20 +288,21 @@ def main():
         K.DETAIL[0] = False
         rows = [v for k, v in prof3.table().items() if k.split(" ")[0].split("[")[0] == dom and v["ms"] > 0]
         if rows:
-            ideal = sum(max(v["flops"] / (PEAK_BF16_TFLOPS * 1e12), v["bytes"] / (PEAK_HBM_GBS * 1e9)) for v in rows)
+            ideal = sum(max(v["flops"] / (PEAK_BF16_TFLOPS * 1e12), v["bytes_8d"] / (PEAK_HBM_GBS * 1e9)) for v in rows)
             roof["attainable_frac"] = round(ideal * 1e3 / sum(v["ms"] for v in rows), 4)
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
     # figure measured for THIS command by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950
-    # correction applied) is read from the committed summary when the workload matches; otherwise null.
+    # correction applied; scripts/profile_round.sh) is read from the committed summary — but only while that summary
+    # was measured on the kernels being run now (it records a digest of csrc/); otherwise null.
     if roof is not None and args.arch == "resnet50" and args.img == 224 and args.batch == 256:
         pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
         if os.path.exists(pmc):
             with open(pmc) as fh:
-                k = json.load(fh)["kernels"].get(roof["kernel"])
-            if k:
+                summary = json.load(fh)
+            k = summary.get("kernels", {}).get(roof["kernel"])
+            if k and summary.get("csrc_digest") == csrc_digest():
                 roof["traffic"] = round(k["hbm_bytes_per_launch"] / 1e9, 3)
                 roof["traffic_unit"] = "GB/launch (PMC, profiles/%s)" % PMC_SUMMARY
-                roof["algorithmic_GB_per_launch"] = round(table[roof["kernel"]]["bytes"] / table[roof["kernel"]]["launches"] / 1e9, 3)
     if rank == 0 and args.profile_table:
         with open(args.profile_table, "w") as fh:
             json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in table.items()}, fh, indent=1)
@@ -245,9 +317,11 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SimCLR %s 3x%dx%d (reference stem), per-GPU batch %d, two-view step: aug + fwd(view1, no grad) + "
-                                   "fwd(view2) + NT-Xent tau=%g + bwd + Adam" % (args.arch, args.img, args.img, args.batch, args.temperature),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.item()),
+            "config": {"workload": "SimCLR %s 3x%dx%d (reference stem), per-GPU batch %d%s, two-view step: aug + fwd(view1, no grad) + "
+                                   "fwd(view2) + NT-Xent tau=%g + bwd + Adam; BASELINE %s"
+                                   % (args.arch, args.img, args.img, args.batch, " with block recompute" if args.recompute else "",
+                                      args.temperature, "configs[2] (global batch 4096)" if world * args.batch == 4096 else "configs[1] per GPU"),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": losses[-1], "loss_first_timed_step": losses[0],
                        "recompute": bool(args.recompute), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

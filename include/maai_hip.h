@@ -297,16 +297,18 @@ int maai_adam_step_multi(const maai_adam_slot* slots, const int* block_slot, con
 
 /* ------------------------------------------------------------------------
  * Two-view augmentation replacing NVIDIA_DALI_Pipelines.py:444-480 for the
- * north-star path: crop window -> nearest resize -> flip -> colour twist.
- * images [B,H,W,3] u8; params [B][8] f32 = x0,y0,cw,ch,flip,brightness,contrast,saturation;
- * out [B,OH,OW,3] u8.
+ * north-star path: crop window -> nearest resize -> flip -> colour twist (brightness, contrast, then hue rotation
+ * and saturation as ONE 3x3 colour matrix in DALI ColorTwist's YIQ form).
+ * images [B,H,W,3] u8; params [B][16] f32 = x0,y0,cw,ch,flip,brightness,contrast, M[3][3] (row major);
+ * out [B,OH,OW,3] u8:  v = ((src - 128)*contrast + 128)*brightness per channel, out = round(clamp(M v, 0, 255)).
  * ------------------------------------------------------------------------ */
 int maai_augment_view_u8(const void* images, const float* params, int B, int H, int W, int OH, int OW, void* out,
                          void* stream);
 /* Philox-free counter hash: fills params for `B` samples from (seed, view) per
- * Contrastive_Learning.py:601-635's ranges. */
+ * Contrastive_Learning.py:601-635's ranges: brightness = (1 - b/2) + b*u, contrast likewise, hue = u*`hue` degrees,
+ * saturation = (1 - s) + s*u; M = YIQ2RGB * R(hue) * diag(1, sat, sat) * RGB2YIQ. */
 int maai_augment_params(float* params, int B, int H, int W, unsigned long long seed, int view, float min_area,
-                        float brightness, float contrast, float saturation, void* stream);
+                        float brightness, float contrast, float saturation, float hue, void* stream);
 
 /* ------------------------------------------------------------------------
  * Foveated retinal processor: the whole DALI graph of NVIDIA_DALI_Pipelines.py:444-480

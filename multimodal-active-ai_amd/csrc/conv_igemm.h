@@ -349,58 +349,51 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
   // the ACTIVATION, not the raw tensor.  Same arithmetic, in the same order, as maai_bn_act_fwd / _fwd2.
   float* xcoef = reinterpret_cast<float*>(smem + RING + (XF == 2 ? NSTAGE * XBS : 0));  // xs | xt (| xs2 | xt2), Cin floats each
   int tkh = 0, tkw = 0, tc0 = 0;  // row-staged layers: tap and channel offset of the next stage to transform
-  auto xf_chunk = [&](T* p, const T* pb, const float* cs, long long goff, bool side) {
-    constexpr int NVX = Vec16<T>::N;
-    Vec16<T> v;
-    v.load(p);
-    float f[NVX];
-    v.get(f);
+  // one stage's coefficients live in registers while its chunks are rewritten (every chunk of a thread carries the
+  // same channels)
+  struct XfCoef {
+    float s[EPC], t[EPC], s2[EPC], t2[EPC];
+  };
+  auto xf_load = [&](const float* cs, XfCoef& q) {
 #pragma unroll
-    for (int e = 0; e < NVX; ++e) f[e] *= cs[e];
-#pragma unroll
-    for (int e = 0; e < NVX; ++e) f[e] += cs[a.Cin + e];
+    for (int e = 0; e < EPC; ++e) {
+      q.s[e] = cs[e];
+      q.t[e] = cs[a.Cin + e];
+    }
     if constexpr (XF == 2) {
-      Vec16<T> w2;
-      w2.load(pb);
-      float g[NVX];
-      w2.get(g);
       if (a.xs2) {
 #pragma unroll
-        for (int e = 0; e < NVX; ++e) g[e] = g[e] * cs[2 * a.Cin + e] + cs[3 * a.Cin + e];
-        w2.set(g);
-        w2.get(g);  // the shortcut as a separate pass would have stored it
-      }
-#pragma unroll
-      for (int e = 0; e < NVX; ++e) f[e] += g[e];
-    }
-    if (a.x_relu) {
-#pragma unroll
-      for (int e = 0; e < NVX; ++e) f[e] = fmaxf(f[e], 0.f);
-    }
-    v.set(f);
-    v.store(p);
-    if constexpr (XF == 2) {
-      if (side) {
-        v.store(reinterpret_cast<T*>(a.x_out) + goff);
-        if (NVX == 8 && a.x_bits) {
-          v.get(f);
-          unsigned b = 0;
-#pragma unroll
-          for (int e = 0; e < NVX; ++e) b |= (f[e] > 0.f ? 1u : 0u) << e;
-          a.x_bits[goff >> 3] = (unsigned char)b;
+        for (int e = 0; e < EPC; ++e) {
+          q.s2[e] = cs[2 * a.Cin + e];
+          q.t2[e] = cs[3 * a.Cin + e];
         }
       }
     }
   };
+  auto xf_chunk = [&](T* p, const T* pb, const XfCoef& q, long long goff, bool side) {
+    Vec16<T> v, w2;
+    v.load(p);
+    if constexpr (XF == 2) w2.load(pb);
+    const bool wb = XF == 2 && side && a.x_bits != nullptr;
+    const unsigned b = XfMath<T>::template run<XF == 2>(v, w2, q.s, q.t, (XF == 2 && a.xs2) ? q.s2 : nullptr, q.t2, a.x_relu, wb);
+    v.store(p);
+    if constexpr (XF == 2) {
+      if (side) {
+        v.store_nt(reinterpret_cast<T*>(a.x_out) + goff);
+        if (wb) a.x_bits[goff >> 3] = (unsigned char)b;
+      }
+    }
+  };
   auto xform_rows = [&](int kt, int slot) {
-    const float* cs = xcoef + (PW ? kt * BK : tc0) + chunk * EPC;
+    XfCoef q;
+    xf_load(xcoef + (PW ? kt * BK : tc0) + chunk * EPC, q);
     const bool side = XF == 2 && a.x_out != nullptr && nb == 0;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = PW ? (ihb[i] >= 0) : ((unsigned)(ihb[i] + tkh) < (unsigned)a.IH && (unsigned)(iwb[i] + tkw) < (unsigned)a.IW);
       if (ok)
         xf_chunk(reinterpret_cast<T*>(smem + slot * STAGE + i * 4096 + tid * 16),
-                 reinterpret_cast<const T*>(smem + RING + slot * XBS + i * 4096 + tid * 16), cs,
+                 reinterpret_cast<const T*>(smem + RING + slot * XBS + i * 4096 + tid * 16), q,
                  PW ? abase[i] + (long long)kt * BK : 0, side);
     }
     if constexpr (!PW) {
@@ -414,14 +407,15 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
   auto xform_halo = [&](int c) {  // the halo of 32-channel chunk c
     char* hb = smem + NSTAGE * STAGE + (c & 1) * HSLOT;
     const int sc = (tid & 3) ^ (((r0 >> 2) & 1) << 1);
-    const float* cs = xcoef + c * BK + sc * EPC;
+    XfCoef q;
+    xf_load(xcoef + c * BK + sc * EPC, q);
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int hp = r0 + 64 * i;
       const int hy = hp / 24, hx = hp - hy * 24;
       const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
       const bool ok = hx < 18 && hy < TH + 2 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      if (ok) xf_chunk(reinterpret_cast<T*>(hb + i * 4096 + tid * 16), nullptr, cs, 0, false);
+      if (ok) xf_chunk(reinterpret_cast<T*>(hb + i * 4096 + tid * 16), nullptr, q, 0, false);
     }
   };
   if constexpr (XF != 0) {

@@ -34,21 +34,10 @@ struct WgradArgs {
   int x_relu;
 };
 
-// act(v*s + t) on a 16-byte chunk, with the arithmetic (and rounding) of maai_bn_act_fwd
+// act(v*s + t) on a 16-byte chunk, with the arithmetic (and rounding) of maai_bn_act_fwd (common.h, XfMath)
 template <typename T>
 __device__ __forceinline__ void xf_apply(Vec16<T>& v, const float* cs, const float* ct, int relu) {
-  constexpr int E = Vec16<T>::N;
-  float f[E];
-  v.get(f);
-#pragma unroll
-  for (int e = 0; e < E; ++e) f[e] *= cs[e];
-#pragma unroll
-  for (int e = 0; e < E; ++e) f[e] += ct[e];
-  if (relu) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) f[e] = fmaxf(f[e], 0.f);
-  }
-  v.set(f);
+  XfMath<T>::template run<false>(v, v, cs, ct, nullptr, nullptr, relu, false);
 }
 
 template <bool ASM>
@@ -575,16 +564,10 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
     }
   }
 
-  // XF: every halo chunk this lane stages carries the same 8 input channels (the swizzle depends on the lane alone)
-  float xcs[8], xct[8];
-  if constexpr (XF) {
-    const int sc = dch ^ (((drow >> 1) & 3) << 1);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      xcs[e] = a.xs[ci0 + sc * 8 + e];
-      xct[e] = a.xt[ci0 + sc * 8 + e];
-    }
-  }
+  // XF: every halo chunk this lane stages carries the same 8 input channels (the swizzle depends on the lane alone);
+  // their coefficients are re-read (L1) per patch rather than held across the MFMA phase, whose 168-register budget
+  // has no room for them
+  const int xf_c = ci0 + (dch ^ (((drow >> 1) & 3) << 1)) * 8;
 
   for (long long pt = p_begin; pt < p_end; ++pt) {
     const int n = (int)(pt / tpi);
@@ -634,6 +617,12 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (XF) {
       // normalise (+ activate) this lane's own halo chunks in place; padding (zero page) stays zero
+      float xcs[8], xct[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xcs[e] = a.xs[xf_c + e];
+        xct[e] = a.xt[xf_c + e];
+      }
 #pragma unroll
       for (int i = 0; i < NDI; ++i) {
         const int qi = widu + 6 * i;

@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
     const long long t = i / OW;
     const int oy = (int)(t % OH);
     const long long n = t / OH;
-    const float* p = params + n * 8;
-    const float x0 = p[0], y0 = p[1], cw = p[2], ch = p[3], flip = p[4], br = p[5], ct = p[6], sat = p[7];
+    const float* p = params + n * 16;
+    const float x0 = p[0], y0 = p[1], cw = p[2], ch = p[3], flip = p[4], br = p[5], ct = p[6];
     const float xs = flip >= 0.5f ? (float)(OW - 1 - ox) : (float)ox;
     // written with explicit fp32 ops in the oracle's order (no fma contraction)
     const float fy = __fadd_rn(y0, __fmul_rn(__fadd_rn((float)oy, 0.5f), __fdiv_rn(ch, (float)OH)));
@@ -472,11 +472,12 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = __fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn((float)s[c], 128.f), ct), 128.f), br);
-    const float grey = __fadd_rn(__fadd_rn(__fmul_rn(0.299f, v[0]), __fmul_rn(0.587f, v[1])), __fmul_rn(0.114f, v[2]));
+    // hue rotation + saturation: one 3x3 colour matrix per sample (DALI ColorTwist's YIQ form), p[7..15] row major
     unsigned char* o = out + i * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      float r = __fadd_rn(grey, __fmul_rn(__fsub_rn(v[c], grey), sat));
+      const float* m = p + 7 + 3 * c;
+      float r = __fadd_rn(__fadd_rn(__fmul_rn(m[0], v[0]), __fmul_rn(m[1], v[1])), __fmul_rn(m[2], v[2]));
       r = fminf(fmaxf(r, 0.f), 255.f);
       r = floorf(__fadd_rn(r, 0.5f));
       o[c] = (unsigned char)fminf(r, 255.f);
@@ -503,7 +504,7 @@ __device__ __forceinline__ float u01(unsigned long long seed, unsigned long long
 }
 
 __global__ void augment_params_kernel(float* __restrict__ params, int B, int H, int W, unsigned long long seed, int view,
-                                      float min_area, float brightness, float contrast, float saturation) {
+                                      float min_area, float brightness, float contrast, float saturation, float hue) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= B) return;
   const unsigned long long base = ((unsigned long long)view << 40) + (unsigned long long)n * 16;
@@ -516,23 +517,40 @@ __global__ void augment_params_kernel(float* __restrict__ params, int B, int H, 
   ch = fminf(ch, (float)H);
   const float x0 = u01(seed, base + 2) * ((float)W - cw);
   const float y0 = u01(seed, base + 3) * ((float)H - ch);
-  float* p = params + (long long)n * 8;
+  float* p = params + (long long)n * 16;
   p[0] = x0;
   p[1] = y0;
   p[2] = cw;
   p[3] = ch;
   p[4] = u01(seed, base + 4) < 0.5f ? 1.f : 0.f;  // CoinFlip(0.5) (NVIDIA_DALI_Pipelines.py:435)
-  // Contrastive_Learning.py:622-630: b = (1 - B/2) + B*u, c likewise, s = (1 - S) + S*u
+  // Contrastive_Learning.py:622-630: b = (1 - B/2) + B*u, c likewise, hue = u*HUE degrees, s = (1 - S) + S*u
   p[5] = (1.f - brightness * 0.5f) + brightness * u01(seed, base + 5);
   p[6] = (1.f - contrast * 0.5f) + contrast * u01(seed, base + 6);
-  p[7] = (1.f - saturation) + saturation * u01(seed, base + 7);
+  const float sat = (1.f - saturation) + saturation * u01(seed, base + 7);
+  const float hdeg = hue * u01(seed, base + 8);
+  // colour matrix M = YIQ2RGB * R(hue) * diag(1, s, s) * RGB2YIQ (ColorTwist, NVIDIA_DALI_Pipelines.py:433,455-462)
+  const float hr = hdeg * 0.017453292519943295f;
+  const float cs = cosf(hr) * sat, sn = sinf(hr) * sat;
+  const float A[3][3] = {{0.299f, 0.587f, 0.114f}, {0.596f, -0.274f, -0.321f}, {0.211f, -0.523f, 0.311f}};   // RGB -> YIQ
+  const float Bm[3][3] = {{1.f, 0.956f, 0.621f}, {1.f, -0.272f, -0.647f}, {1.f, -1.107f, 1.705f}};           // YIQ -> RGB
+  float T[3][3];  // R(hue) * diag(1, s, s) * A
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    T[0][j] = A[0][j];
+    T[1][j] = cs * A[1][j] - sn * A[2][j];
+    T[2][j] = sn * A[1][j] + cs * A[2][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) p[7 + 3 * i + j] = Bm[i][0] * T[0][j] + Bm[i][1] * T[1][j] + Bm[i][2] * T[2][j];
 }
 
 extern "C" int maai_augment_params(float* params, int B, int H, int W, unsigned long long seed, int view, float min_area,
-                                   float brightness, float contrast, float saturation, void* stream) {
+                                   float brightness, float contrast, float saturation, float hue, void* stream) {
   MAAI_CHECK_ARG(params && B > 0 && H > 0 && W > 0 && min_area > 0.f && min_area <= 1.f, "augment_params: bad arguments");
   hipLaunchKernelGGL(augment_params_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), params, B, H, W, seed, view, min_area,
-                     brightness, contrast, saturation);
+                     brightness, contrast, saturation, hue);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

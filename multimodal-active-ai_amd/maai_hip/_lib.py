@@ -78,7 +78,7 @@ SIGNATURES = {
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
     "maai_augment_view_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maai_foveate_views_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
-    "maai_augment_params": (c_i, [c_p, c_i, c_i, c_i, c_ull, c_i, c_f, c_f, c_f, c_f, c_p]),
+    "maai_augment_params": (c_i, [c_p, c_i, c_i, c_i, c_ull, c_i, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
 
 _LIB = None

@@ -255,14 +255,51 @@ _EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0"}
 # (conv1 -> conv2 -> conv3, and the stem -> layer1); "join": the residual join relu(bn3(y3) + shortcut) is formed by
 # the NEXT block's conv1, which hands the joined activation back once for the shortcut and the backward pass.
 # Bit-identical to the materialised path (tests/test_gpu_xf.py); MAAI_LAZY=0 / MAAI_JOIN=0 switch them off.
-_LAZY = {"enabled": os.environ.get("MAAI_LAZY", "1") != "0", "join": os.environ.get("MAAI_JOIN", "1") != "0"}
+# WHERE it pays was measured per layer shape of the benchmark (scripts/xf_ab.py, B = 256, interleaved in one process;
+# gain = BatchNorm pass + plain launch - lazy launch, per launch):
+#   forward, one raw tensor:  stem -> layer1 +0.61 ms, layer1 conv2 (3x3 C64 @224) +0.29, layer1 conv3 +0.25,
+#       layer2.0 conv2 (3x3 stride 2, C128 @224) +0.64, layer2 conv3 +0.16, layer2 conv2 @112 -0.36,
+#       layer3 -0.46 / +0.02, layer4 -0.55 / -0.02  (the transform is vector work in the GEMM's K loop, repeated for
+#       every re-staging of an element: it hides under HBM-bound layers and costs compute-bound ones their MFMA time)
+#   residual join in the next conv1:  layer1 +0.76 (the join then runs AT the HBM rate), layer2 +0.11, layer3 -0.29, layer4 -0.72
+#   weight gradient on a raw tensor (no pass saved, the transform is pure cost):  3x3 +0.65..0.81 ms, 1x1 C64 -0.05,
+#       C128 +0.44, C256 +0.48
+# Hence ("auto"): the consumer of a raw tensor forms it on load when it is a pointwise layer with <= 64 input channels
+# (<= 128 when no backward pass will follow), or — without a backward pass only — a 3x3 layer with <= 64 channels or a
+# stride-2 3x3 layer with <= 128; a block's conv1 joins on load up to 512 input channels.  "all": wherever possible
+# (tests).  MAAI_LAZY_POLICY overrides.
+_LAZY = {"enabled": os.environ.get("MAAI_LAZY", "1") != "0", "join": os.environ.get("MAAI_JOIN", "1") != "0",
+         "policy": os.environ.get("MAAI_LAZY_POLICY", "auto")}
 
 
-def set_lazy(lazy=None, join=None):
+def set_lazy(lazy=None, join=None, policy=None):
     if lazy is not None:
         _LAZY["enabled"] = bool(lazy)
     if join is not None:
         _LAZY["join"] = bool(join)
+    if policy is not None:
+        if policy not in ("auto", "all"):
+            raise ValueError("lazy policy must be 'auto' or 'all'")
+        _LAZY["policy"] = policy
+
+
+def _lazy_pays(consumers, keep):
+    """Should a unit hand its raw output to ``consumers`` (convolutions) instead of running its BatchNorm pass?"""
+    if not _LAZY["enabled"]:
+        return False
+    if _LAZY["policy"] == "all":
+        return True
+    for conv in consumers:
+        k, cin, stride = conv.kernel_size[0], conv.in_channels, conv.stride[0]
+        if k == 1:
+            ok = cin <= (64 if keep else 128)
+        elif k == 3:
+            ok = (not keep) and (cin <= 64 or (stride == 2 and cin <= 128))
+        else:
+            ok = False
+        if not ok:
+            return False
+    return True
 
 
 def materialise(x):
@@ -683,8 +720,8 @@ def _joins_on_load(blk, dtype):
     """Can ``blk``'s first convolution form the previous block's residual join on load?"""
     c1 = blk.conv1
     return (_LAZY["enabled"] and _LAZY["join"] and _is_bottleneck(blk) and c1.kernel_size == (1, 1) and c1.stride == (1, 1)
-            and c1.padding == (0, 0) and c1.in_channels <= 2048 and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0
-            and not _fusable(c1, "fwd"))
+            and c1.padding == (0, 0) and c1.in_channels <= (2048 if _LAZY["policy"] == "all" else 512)
+            and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0 and not _fusable(c1, "fwd"))
 
 
 def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False):
@@ -693,17 +730,17 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False):
     block's conv1 to form.  Returns (out, (r1, r2, r3, rd), xin tensor or single-tensor Lazy as materialised here,
     1-bit mask of xin or None)."""
     g1, g2, g3, gd = given if given is not None else (None, None, None, None)
-    lazy = _LAZY["enabled"]
     side = {}
     needs_identity = blk.downsample is None
     if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or (xin.b is not None and not _joins_on_load(blk, dtype))):
         xin = materialise(xin)   # the identity shortcut reads it / conv1 cannot join it
-    o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=lazy, side=side)
+    nxt = blk.conv2
+    o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=_lazy_pays([nxt], keep), side=side)
     xin_bits = side.get("bits")
     if isinstance(xin, K.Lazy) and xin.b is not None:
         xin = side["joined"]     # conv1 formed the join and handed it back
     if _is_bottleneck(blk):
-        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=lazy)
+        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=_lazy_pays([blk.conv3], keep))
         last_conv, last_bn = blk.conv3, blk.bn3
     else:  # BasicBlock
         r2 = None
@@ -730,8 +767,8 @@ def backbone_fwd(resnet, x, dtype, keep):
     blocks = list(_blocks(resnet))
     # the stem's activation is formed on load by layer1's first convolutions when that block has a projection
     # shortcut (an identity shortcut would read the tensor itself)
-    stem_lazy = (_LAZY["enabled"] and bool(blocks) and blocks[0].downsample is not None and not _fusable(blocks[0].conv1, "fwd")
-                 and not _fusable(blocks[0].downsample[0], "fwd"))
+    stem_lazy = (bool(blocks) and blocks[0].downsample is not None and not _fusable(blocks[0].conv1, "fwd")
+                 and not _fusable(blocks[0].downsample[0], "fwd") and _lazy_pays([blocks[0].conv1, blocks[0].downsample[0]], keep))
     K.FLOPS_SCALE[0] = (49.0 * cin) / (wq.shape[1] * wq.shape[2] * wq.shape[3])  # executed K includes zero padding
     out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form, lazy_out=stem_lazy)
     K.FLOPS_SCALE[0] = 1.0

@@ -62,21 +62,24 @@ class profile(object):
         torch.cuda.synchronize()
 
     def table(self):
+        """bytes = what the launch moves as built (every tensor its epilogue reads or writes); bytes_8d = SURVEY §8(d)'s
+        algorithmic figure for a convolution: its input once + its output once."""
         out = {}
-        for name, flops, nbytes, e0, e1 in self.records:
-            t = out.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        for name, flops, nbytes, b8d, e0, e1 in self.records:
+            t = out.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, bytes_8d=0.0, launches=0))
             t["ms"] += e0.elapsed_time(e1)
             t["flops"] += flops
             t["bytes"] += nbytes
+            t["bytes_8d"] += b8d
             t["launches"] += 1
         return out
 
 
 class _timed(object):
-    __slots__ = ("name", "flops", "bytes", "e0")
+    __slots__ = ("name", "flops", "bytes", "b8d", "e0")
 
-    def __init__(self, name, flops, nbytes):
-        self.name, self.flops, self.bytes = name, flops, nbytes
+    def __init__(self, name, flops, nbytes, b8d=None):
+        self.name, self.flops, self.bytes, self.b8d = name, flops, nbytes, (nbytes if b8d is None else b8d)
 
     def __enter__(self):
         if _PROF is not None:
@@ -87,7 +90,7 @@ class _timed(object):
         if _PROF is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _PROF.append((self.name, self.flops, self.bytes, self.e0, e1))
+            _PROF.append((self.name, self.flops, self.bytes, self.b8d, self.e0, e1))
 
 
 # ----------------------------------------------------------------------------
@@ -175,7 +178,8 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     if relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
         raise MaaiError("conv2d: relu_mask must have the output's shape and dtype")
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
-                es * (x.numel() + w.numel() + m * d.Cout * (1 + (1 if accumulate else 0) + (1 if relu_mask is not None else 0)))):
+                es * (x.numel() + w.numel() + m * d.Cout * (1 + (1 if accumulate else 0) + (1 if relu_mask is not None else 0))),
+                es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), _dt(x), _stream()),
               "maai_conv2d_igemm")
     return (out, part) if stats else out
@@ -199,7 +203,7 @@ def _conv2d_lazy(xf, w, stride, pad_h, pad_w, stats, join_out, join_bits):
     es = x.element_size()
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[xf%d] M%d Cin%d Cout%d k%dx%d s%d os1 acc0" % (2 if xf.b is not None else 1, m, d.Cin, d.Cout, d.KH, d.KW, d.stride)
     nbytes = es * (x.numel() * (1 + (1 if xf.b is not None else 0) + (1 if jo is not None else 0)) + w.numel() + m * d.Cout) + (0 if jb is None else jb.numel())
-    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes):
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes, es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), None, C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")
     ret = (out, part) if stats else (out,)
@@ -254,7 +258,7 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
                 es * (x.numel() * (1 if axf is None else (3 if axf[4] is not None else 2)) + w.numel()
                       + m * d.Cout * (2 + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
-                + (m * d.Cout // 8 if mask_bits else 0)):
+                + (m * d.Cout // 8 if mask_bits else 0), es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")
     return out
@@ -268,7 +272,7 @@ def _conv_fused(x, w, stride, pad_h, pad_w, mode, out, part, p0=None, p1=None, p
     es = x.element_size()
     nbytes = es * (x.numel() + w.numel() + (m * d.Cout if out is not None else 0) + (t.numel() if t is not None else 0))
     nm = name if not DETAIL[0] else "%s[epi%d] M%d Cin%d Cout%d k%dx%d" % (name, mode, m, d.Cin, d.Cout, d.KH, d.KW)
-    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes):
+    with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0], nbytes, es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), None, C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")
     return d
@@ -729,17 +733,20 @@ def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step):
 
 def augment_view_u8(images, params, oh, ow):
     _gpu(images, params)
+    if params.dtype != torch.float32 or params.dim() != 2 or params.shape[1] != 16 or params.shape[0] != images.shape[0]:
+        raise MaaiError("augment_view_u8: params must be float32 [B,16]")
     b, h, w, _ = images.shape
     out = torch.empty((b, oh, ow, 3), dtype=torch.uint8, device=images.device)
     check(lib().maai_augment_view_u8(_p(images), _p(params), b, h, w, oh, ow, _p(out), _stream()), "maai_augment_view_u8")
     return out
 
 
-def augment_params(b, h, w, seed, view, device, min_area=0.1, brightness=0.8, contrast=0.8, saturation=0.8):
-    params = torch.empty((b, 8), dtype=torch.float32, device=device)
+def augment_params(b, h, w, seed, view, device, min_area=0.1, brightness=1.0, contrast=1.0, saturation=0.5, hue=90.0):
+    """[b,16] f32 crop / flip / colour-twist parameters (defaults: the driver's, Contrastive_Learning.py:164-171)."""
+    params = torch.empty((b, 16), dtype=torch.float32, device=device)
     _gpu(params)
     check(lib().maai_augment_params(_p(params), b, h, w, int(seed), int(view), float(min_area), float(brightness),
-                                    float(contrast), float(saturation), _stream()), "maai_augment_params")
+                                    float(contrast), float(saturation), float(hue), _stream()), "maai_augment_params")
     return params
 
 

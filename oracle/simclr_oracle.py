@@ -437,14 +437,15 @@ def train_step(sd, opt, x1, x2, arch, temperature, lr, storage="fp32", pool=None
 # written so that the HIP kernel can match it bit-for-bit on u8 output.
 # ----------------------------------------------------------------------------
 def augment_view(img: torch.Tensor, params: torch.Tensor, out_hw: Tuple[int, int]) -> torch.Tensor:
-    """img [H,W,3] u8; params f32[8] = (x0, y0, cw, ch, flip, brightness,
-    contrast, saturation) in source-pixel units; nearest-neighbour resize of the
-    crop window to out_hw, horizontal flip, then colour twist
-        v' = clamp(((v - 128)*contrast + 128) * brightness) ; grey-mix for saturation
-    evaluated in fp32 with round-half-up to u8."""
+    """img [H,W,3] u8; params f32[16] = (x0, y0, cw, ch, flip, brightness, contrast, M[3][3] row major) in
+    source-pixel units; nearest-neighbour resize of the crop window to out_hw, horizontal flip, then colour twist
+        v = ((src - 128)*contrast + 128) * brightness ;  out = clamp(M v)
+    (M = hue rotation and saturation in YIQ, Contrastive_Learning.py:622-630 / DALI ColorTwist) evaluated in fp32,
+    one rounding per operation, products summed left to right, round-half-up to u8."""
     H, W, _ = img.shape
     oh, ow = out_hw
-    x0, y0, cw, ch, flip, br, ct, sat = [float(v) for v in params]
+    x0, y0, cw, ch, flip, br, ct = [float(v) for v in params[:7]]
+    M = params[7:16].to(torch.float32).reshape(3, 3)
     ys = torch.arange(oh, dtype=torch.float32)
     xs = torch.arange(ow, dtype=torch.float32)
     if flip >= 0.5:
@@ -452,11 +453,20 @@ def augment_view(img: torch.Tensor, params: torch.Tensor, out_hw: Tuple[int, int
     sy = torch.floor(torch.tensor(y0, dtype=torch.float32) + (ys + 0.5) * (torch.tensor(ch, dtype=torch.float32) / oh)).clamp(0, H - 1).long()
     sx = torch.floor(torch.tensor(x0, dtype=torch.float32) + (xs + 0.5) * (torch.tensor(cw, dtype=torch.float32) / ow)).clamp(0, W - 1).long()
     v = img[sy][:, sx].to(torch.float32)  # [oh, ow, 3]
-    br32, ct32, sat32 = (torch.tensor(t, dtype=torch.float32) for t in (br, ct, sat))
+    br32, ct32 = (torch.tensor(t, dtype=torch.float32) for t in (br, ct))
     v = ((v - 128.0) * ct32 + 128.0) * br32
-    grey = 0.299 * v[..., 0] + 0.587 * v[..., 1] + 0.114 * v[..., 2]
-    v = grey[..., None] + (v - grey[..., None]) * sat32
-    return torch.floor(v.clamp(0.0, 255.0) + 0.5).clamp(0, 255).to(torch.uint8)
+    out = torch.stack([(M[c, 0] * v[..., 0] + M[c, 1] * v[..., 1]) + M[c, 2] * v[..., 2] for c in range(3)], dim=-1)
+    return torch.floor(out.clamp(0.0, 255.0) + 0.5).clamp(0, 255).to(torch.uint8)
+
+
+def colour_matrix(hue_deg: float, saturation: float) -> torch.Tensor:
+    """fp64 reference of the matrix maai_augment_params builds: YIQ2RGB * R(hue) * diag(1, s, s) * RGB2YIQ."""
+    import math
+    a = torch.tensor([[0.299, 0.587, 0.114], [0.596, -0.274, -0.321], [0.211, -0.523, 0.311]], dtype=torch.float64)
+    b = torch.tensor([[1.0, 0.956, 0.621], [1.0, -0.272, -0.647], [1.0, -1.107, 1.705]], dtype=torch.float64)
+    h = math.radians(hue_deg)
+    rot = torch.tensor([[1, 0, 0], [0, math.cos(h), -math.sin(h)], [0, math.sin(h), math.cos(h)]], dtype=torch.float64)
+    return b @ rot @ torch.diag(torch.tensor([1.0, saturation, saturation], dtype=torch.float64)) @ a
 
 
 # ----------------------------------------------------------------------------

@@ -497,6 +497,35 @@ def test_augment_bit_exact(K):
     for i in range(6):
         ref = O.augment_view(imgs[i], pc[i], (32, 32))
         assert torch.equal(out[i], ref), i
+    # hue / saturation jitter (Contrastive_Learning.py:622-630): the colour matrix is YIQ2RGB R(hue) diag(1,s,s) RGB2YIQ
+    # for SOME hue in [0, 90] degrees and saturation in [0.5, 1]; recover them from the matrix and compare with fp64
+    A = torch.tensor([[0.299, 0.587, 0.114], [0.596, -0.274, -0.321], [0.211, -0.523, 0.311]], dtype=torch.float64)
+    B = torch.tensor([[1.0, 0.956, 0.621], [1.0, -0.272, -0.647], [1.0, -1.107, 1.705]], dtype=torch.float64)
+    hues = []
+    for i in range(6):
+        M = pc[i, 7:16].double().reshape(3, 3)
+        R = torch.linalg.solve(B, M) @ torch.linalg.inv(A)      # = R(hue) diag(1, s, s)
+        sat = float((R[1, 1] ** 2 + R[2, 1] ** 2).sqrt())
+        hue = float(torch.atan2(R[2, 1], R[1, 1])) * 180.0 / np.pi
+        assert 0.5 - 1e-3 <= sat <= 1.0 + 1e-3 and -1e-2 <= hue <= 90.0 + 1e-2, (sat, hue)
+        np.testing.assert_allclose(M.numpy(), O.colour_matrix(hue, sat).numpy(), atol=2e-5)
+        hues.append(hue)
+    assert max(hues) - min(hues) > 5.0   # the hue really is jittered per sample
+    # no jitter requested -> no hue rotation, unit saturation
+    p0 = K.augment_params(4, 64, 48, seed=3, view=0, device="cuda", brightness=0.0, contrast=0.0, saturation=0.0, hue=0.0).cpu()
+    assert torch.equal(p0[:, 5], torch.ones(4)) and torch.equal(p0[:, 6], torch.ones(4))
+    np.testing.assert_allclose(p0[0, 7:16].double().reshape(3, 3).numpy(), O.colour_matrix(0.0, 1.0).numpy(), atol=1e-6)
+    # a pure hue rotation of 90 degrees on a saturated colour, against the fp64 matrix
+    ph = p0[:1].clone()
+    ph[0, :5] = torch.tensor([0.0, 0.0, 48.0, 64.0, 0.0])
+    ph[0, 7:16] = O.colour_matrix(90.0, 1.0).float().reshape(-1)
+    red = torch.zeros(1, 64, 48, 3, dtype=torch.uint8)
+    red[..., 0] = 200
+    red[..., 1] = 40
+    red[..., 2] = 30
+    oh = K.augment_view_u8(red.cuda(), ph.cuda(), 8, 8).cpu()[0, 0, 0].double()
+    want = (O.colour_matrix(90.0, 1.0) @ torch.tensor([200.0, 40.0, 30.0], dtype=torch.float64)).clamp(0, 255)
+    assert (oh - want).abs().max() <= 1.0, (oh, want)
     # different view id -> different parameters, same seed+view -> identical (counter-based)
     p2 = K.augment_params(6, 64, 48, seed=77, view=2, device="cuda").cpu()
     p1 = K.augment_params(6, 64, 48, seed=77, view=1, device="cuda").cpu()

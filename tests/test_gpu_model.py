@@ -425,7 +425,7 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
     try:
         for tag, (lazy, join, rec) in (("plain", (False, False, False)), ("lazy", (True, False, False)), ("join", (True, True, False)),
                                        ("join+recompute", (True, True, True))):
-            engine.set_lazy(lazy, join)
+            engine.set_lazy(lazy, join, "all")
             engine.set_recompute(rec)
             m = _build(mods, arch, cm, head_in, shape[0], shape[2:], 0.5)
             m.train()
@@ -444,7 +444,7 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
                 feat_ng, _ = engine.backbone_fwd(m.f, x, dtype, keep=False)   # the no-grad view of the SimCLR step
             res[tag] = (feat.float().cpu(), named, held, bufs, feat_ng.float().cpu())
     finally:
-        engine.set_lazy(True, True)
+        engine.set_lazy(True, True, "auto")
         engine.set_recompute(False)
     for tag in ("lazy", "join", "join+recompute"):
         assert torch.equal(res[tag][0], res["plain"][0]), tag
