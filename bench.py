@@ -130,9 +130,11 @@ def synthetic_images(b, size, device, seed):
 def make_step(args, model, opt, device, rank, world):
     import Objective
     from maai_hip import kernels as K
-    from maai_hip.dist import GradAllReduce
+    from maai_hip import engine
+    from maai_hip.dist import GradReducer
     images = synthetic_images(args.batch, args.img, device, 1234 + rank)
-    sync = GradAllReduce(list(model.parameters())) if world > 1 else None
+    # N > 1: gradient buckets are all-reduced from inside the backward pass (side stream), not after it
+    engine.set_grad_hook(GradReducer(list(model.parameters())) if world > 1 else None)
     state = {"it": 0}
 
     def step():
@@ -149,8 +151,6 @@ def make_step(args, model, opt, device, rank, world):
                                                 local_rank=rank, world_size=world, device=device)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        if sync is not None:
-            sync()
         opt.step()
         return loss
     return step

@@ -50,14 +50,22 @@ class SimCLR_Module(nn.Module):
             raise RuntimeError("SimCLR_Module: expected %d views of [%d,%d,%d,3], got %s" %
                                (len(views), self.batch_size, self.img_size[0], self.img_size[1], tuple(views[0].shape)))
         if _is_hip_backbone(self.f) and _is_hip_head(self.g) and views[0].dtype == torch.uint8:
-            return _engine.fused_forward(self.f, self.g, [v.contiguous() for v in views], self.head_pool)
+            out = _engine.fused_forward(self.f, self.g, [v.contiguous() for v in views], self.head_pool)
+            if self.training:
+                # N > 1: the cross-replica gather of this view's embedding (Objective.py:102-114) starts now, on a
+                # side stream — view 1's then runs under the whole view-2 forward (no-op at world size 1)
+                _loss.prefetch_embedding(out)
+            return out
         x = torch.stack(views).permute(1, 0, 4, 2, 3).reshape(self.batch_size, -1, self.img_size[0], self.img_size[1]).float()
         return self.g(self.f(x.contiguous()))
 
     def forward_tensor(self, x):
         """g(f(x)) for an already packed NCHW fp32 batch (BASELINE cfg1 feeds randn(64,3,32,32))."""
         if _is_hip_backbone(self.f) and _is_hip_head(self.g):
-            return _engine.fused_forward(self.f, self.g, x, self.head_pool)
+            out = _engine.fused_forward(self.f, self.g, x, self.head_pool)
+            if self.training:
+                _loss.prefetch_embedding(out)
+            return out
         return self.g(self.f(x))
 
 

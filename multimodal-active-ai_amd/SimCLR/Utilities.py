@@ -8,14 +8,14 @@ class AverageMeter(object):
     """Tracks the latest sample (``val``), the weighted total (``sum``), the weight (``count``) and their ratio
     (``avg``) — the four attributes the training and validation loops read."""
 
-    _FIELDS = ("val", "sum", "count", "avg")
-
     def __init__(self):
         self.reset()
 
     def reset(self):
-        for name in self._FIELDS:
-            setattr(self, name, 0)
+        self.val = 0
+        self.sum = 0
+        self.count = 0
+        self.avg = 0
 
     def update(self, val, n=1):
         total = self.sum + val * n

@@ -332,9 +332,89 @@ def _lazy_input_ok(x, conv, dtype):
     return True
 
 
-def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None,
-             lazy_out=False, side=None):
-    """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).
+def _drive(gen, reduce=True):
+    """Run a unit generator to completion; it yields its local fp64 sums at most once when a cross-rank exchange is
+    due and continues with the reduced ones."""
+    try:
+        sums = next(gen)
+    except StopIteration as e:
+        return e.value
+    if reduce:
+        dist.all_reduce(sums)
+    try:
+        gen.send(sums)
+    except StopIteration as e:
+        return e.value
+    raise MaaiError("a unit asked for more than one statistics exchange")
+
+
+def _drive_pair(ga, gb):
+    """Two units whose statistics are due at the same point (the two BatchNorms that meet at a projection shortcut,
+    forward and backward): ONE all-reduce over both sum vectors instead of two."""
+    ra = rb = None
+    sa = sb = None
+    try:
+        sa = next(ga)
+    except StopIteration as e:
+        ra = (e.value,)
+    try:
+        sb = next(gb)
+    except StopIteration as e:
+        rb = (e.value,)
+    if sa is not None and sb is not None:
+        both = torch.cat([sa, sb])
+        dist.all_reduce(both)
+        sa, sb = both[:sa.numel()], both[sa.numel():]
+    elif sa is not None:
+        dist.all_reduce(sa)
+    elif sb is not None:
+        dist.all_reduce(sb)
+    for which, g, sm in ((0, ga, sa), (1, gb, sb)):
+        if sm is None:
+            continue
+        try:
+            g.send(sm)
+            raise MaaiError("a unit asked for more than one statistics exchange")
+        except StopIteration as e:
+            if which == 0:
+                ra = (e.value,)
+            else:
+                rb = (e.value,)
+    return ra[0], rb[0]
+
+
+class _Boxed(object):
+    """Generator wrapper: when the wrapped unit finishes, its output (the deferred shortcut branch) is put in ``box``,
+    where the unit that applies it (created with ``branch=box``) finds it on resumption."""
+
+    def __init__(self, gen, box):
+        self.gen, self.box = gen, box
+
+    def __next__(self):
+        try:
+            return next(self.gen)
+        except StopIteration as e:
+            self.box[0] = e.value[0]
+            raise
+
+    def send(self, v):
+        try:
+            return self.gen.send(v)
+        except StopIteration as e:
+            self.box[0] = e.value[0]
+            raise
+
+
+def unit_fwd(*args, **kwargs):
+    """out = act(BN(conv(x)) (+ residual)): see ``_unit_fwd_gen`` (this drives it, exchanging SyncBatchNorm statistics)."""
+    return _drive(_unit_fwd_gen(*args, **kwargs))
+
+
+def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None,
+                  lazy_out=False, side=None):
+    """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).  A generator: with SyncBatchNorm over
+    more than one rank it yields its local fp64 sums once and resumes with the all-reduced ones (``_drive``);
+    ``branch`` may be a one-element list filled in before that resumption (``_drive_pair``).
     ``x`` may be a ``kernels.Lazy`` activation (formed on load).  If it is a two-tensor join, the joined activation
     (and, bf16 with gradients, its 1-bit ReLU mask) comes back in ``side["joined"]`` / ``side["bits"]``.
     ``lazy_out``: do not run this unit's BatchNorm pass — return a ``kernels.Lazy`` (rec.out stays None until the
@@ -389,7 +469,7 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
         sums = K.reduce_partials(part)
         world = _sync_world(bn)
         if world > 1:
-            dist.all_reduce(sums)
+            sums = yield sums
             count *= world
         mom = bn.momentum
         if bn.track_running_stats and bn.running_mean is not None:
@@ -411,6 +491,8 @@ def unit_fwd(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defe
             y = conv_x(False)
         mean = invstd = None
         count, world = x.numel() // x.shape[-1] if fused else y.numel() // y.shape[-1], 1
+    if isinstance(branch, list):
+        branch = branch[0]   # the shortcut branch, finalised by the same exchange (_drive_pair)
     xb = side["joined"] if (side is not None and isinstance(x, K.Lazy) and x.b is not None) else x  # what the backward reads
     if fused:
         out = K.conv2d_bn_act(x, wq, scale, shift, residual, relu)
@@ -576,6 +658,11 @@ def _grad_to_reference(rec, dw):
 
 
 def unit_bwd_coeffs(rec, dout, grads, dtype, presums=None):
+    """BatchNorm-backward coefficients (k1, k2, k3) of a unit: see ``_unit_bwd_coeffs_gen``."""
+    return _drive(_unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums))
+
+
+def _unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums=None):
     """BatchNorm-backward coefficients (k1, k2, k3) of a unit — dy = k1*dz - k2 - k3*y — from the sums of dz and
     dz*(y - mean) (``presums`` if the producer of dz reduced them, else one reduction pass); stores the BatchNorm
     parameter gradients in ``grads``."""
@@ -593,7 +680,7 @@ def unit_bwd_coeffs(rec, dout, grads, dtype, presums=None):
         if rec.world > 1:
             # torch SyncBatchNorm: weight/bias gradients from the LOCAL sums, dx from the all-reduced ones
             dgamma, dbeta, _, _, _ = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
-            dist.all_reduce(sums)
+            sums = yield sums.clone() if presums is not None else sums   # (never all-reduce a caller's tensor in place)
             _, _, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
         else:
             dgamma, dbeta, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
@@ -747,9 +834,12 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False):
         last_conv, last_bn = blk.conv2, blk.bn2
     rd = None
     if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
-        # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored
-        br, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True, given=gd)
-        out, r3 = unit_fwd(o, last_conv, last_bn, True, None, dtype, keep, branch=br, given=g3, lazy_out=lazy_out)
+        # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored; with
+        # SyncBatchNorm the two units' statistics travel in ONE all-reduce (_drive_pair)
+        box = [None]
+        gen_d = _unit_fwd_gen(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True, given=gd)
+        gen_3 = _unit_fwd_gen(o, last_conv, last_bn, True, None, dtype, keep, branch=box, given=g3, lazy_out=lazy_out)
+        (br, rd), (out, r3) = _drive_pair(_Boxed(gen_d, box), gen_3)
     else:
         if blk.downsample is not None:
             idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, given=gd)
@@ -798,8 +888,7 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
     dyd = None
     if rd is not None and _DUAL_BN["enabled"] and not r3.fused and not rd.fused:
         # both branches receive the same gradient: one pass reads it once and writes both dy
-        k3 = unit_bwd_coeffs(r3, dout, grads, dtype, presums)
-        kd = unit_bwd_coeffs(rd, dout, grads, dtype)
+        k3, kd = _drive_pair(_unit_bwd_coeffs_gen(r3, dout, grads, dtype, presums), _unit_bwd_coeffs_gen(rd, dout, grads, dtype))
         dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
         d, s = unit_bwd(r3, None, grads, dtype, below=r2 if r2 is not None else r1, dy=dy3)
         del dy3
@@ -837,8 +926,19 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
     return dx, sp
 
 
+# N > 1: an object with ready(grads) / finish(grads) (maai_hip.dist.GradReducer).  The hand-written backward calls
+# ready() after the head and after every block, so a bucket's all-reduce starts on the side stream while the blocks
+# below are still being differentiated.
+_GRAD_HOOK = [None]
+
+
+def set_grad_hook(hook):
+    _GRAD_HOOK[0] = hook
+
+
 def backbone_bwd(tape, dout, grads, dtype):
     """``dout``: gradient wrt the layer4 map, NOT yet masked."""
+    hook = _GRAD_HOOK[0]
     last = tape[-1]
     dout = relu_mask_grad(dout, last[4] if last[0] == "ckpt" else (last[3].out if last[0] == "block" else last[1].out))
     sums = None
@@ -858,10 +958,14 @@ def backbone_bwd(tape, dout, grads, dtype):
             dout, sums = block_bwd(("block",) + recs, dout, grads, dtype, prev=None, presums=sums)
             tape[i] = None
             del recs
+            if hook is not None:
+                hook.ready(grads)
             continue
         below = tape[i - 1]
         prev = below[1] if below[0] == "stem" else (below[3] if below[0] == "block" else None)
         dout, sums = block_bwd(entry, dout, grads, dtype, prev=prev, presums=sums)
+        if hook is not None:
+            hook.ready(grads)
 
 
 # ----------------------------------------------------------------------------
@@ -970,10 +1074,15 @@ class _FusedFn(torch.autograd.Function):
         if not ctx.keep:
             raise MaaiError("backward through a forward that ran without gradients")
         grads = {}
+        hook = _GRAD_HOOK[0]
         dfeat = head_bwd(ctx.g, ctx.htape, dz, grads, ctx.dtype)
+        if hook is not None:
+            hook.ready(grads)
         backbone_bwd(ctx.tape, dfeat, grads, ctx.dtype)
         if grads.pop("_side", False):
             torch.cuda.current_stream().wait_stream(_side_stream())
+        if hook is not None:
+            hook.finish(grads)   # the compute stream continues behind the last bucket; the tensors below hold the averages
         ctx.tape = ctx.htape = None
         return (None, None, None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
 

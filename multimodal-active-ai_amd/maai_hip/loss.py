@@ -6,6 +6,7 @@ differentiable single-process loss."""
 import torch
 import torch.distributed as dist
 
+from . import dist as D
 from . import kernels as K
 from ._lib import MaaiError
 
@@ -20,17 +21,37 @@ def gather_normalized(z1, z2, world_size, group=None):
     return out[:, :d].contiguous(), out[:, d:].contiguous()
 
 
+def gather_one(z, world_size, group=None):
+    out = torch.empty((world_size * z.shape[0], z.shape[1]), dtype=z.dtype, device=z.device)
+    dist.all_gather_into_tensor(out, z.contiguous(), group=group)
+    return out
+
+
+def prefetch_embedding(h):
+    """Start the all-gather of normalize(h) on the side stream (maai_hip.dist.prefetch_embedding); a later
+    contrastive_loss(h.data, ...) / contrastive_loss(..., h) with hidden_norm=True picks it up."""
+    if D.is_distributed() and h.is_cuda and h.dim() == 2:
+        D.prefetch_embedding(h, lambda t: K.ntxent_normalize(t, True))
+
+
 class _NTXentFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h1, h2, hidden_norm, temperature, rank, world_size):
         if not h1.is_cuda:
             raise MaaiError("contrastive_loss: the HIP path needs HIP tensors (got %s); there is no CPU fallback" % h1.device)
         h1c, h2c = h1.contiguous().float(), h2.contiguous().float()
-        z1, inv1 = K.ntxent_normalize(h1c, hidden_norm)
-        z2, inv2 = K.ntxent_normalize(h2c, hidden_norm)
         b = h1c.shape[0]
+        # gathers that SimCLR_Module.forward started on the side stream (view 1's ran under the view-2 forward)
+        pre1 = D.take_prefetched(h1, world_size) if (world_size > 1 and hidden_norm) else None
+        pre2 = D.take_prefetched(h2, world_size) if (world_size > 1 and hidden_norm) else None
+        z1, inv1 = (pre1[0], pre1[1]) if pre1 is not None else K.ntxent_normalize(h1c, hidden_norm)
+        z2, inv2 = (pre2[0], pre2[1]) if pre2 is not None else K.ntxent_normalize(h2c, hidden_norm)
         if world_size > 1:
-            Z1, Z2 = gather_normalized(z1, z2, world_size)
+            if pre1 is None and pre2 is None:
+                Z1, Z2 = gather_normalized(z1, z2, world_size)
+            else:
+                Z1 = pre1[2] if pre1 is not None else gather_one(z1, world_size)
+                Z2 = pre2[2] if pre2 is not None else gather_one(z2, world_size)
             off = rank * b
         else:
             Z1, Z2, off = z1, z2, 0

@@ -21,7 +21,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import simclr_oracle as O
     from maai_hip import loss as L
+    from maai_hip import dist as D
     from maai_hip.dist import GradAllReduce
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-active-ai_amd", "SimCLR"))
+    import Utilities
     torch.manual_seed(1234)
     b, d = 8, 128
     H1, H2 = torch.randn(world * b, d), torch.randn(world * b, d)
@@ -34,9 +37,55 @@ def _worker(rank, world, port, q):
     params = [torch.nn.Parameter(torch.zeros(7, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 2, 2))]
     for i, p in enumerate(params):
         p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-    GradAllReduce(params, bucket_bytes=64)()
+    red = GradAllReduce(params, bucket_bytes=64)
+    red()
     avg = [p.grad.flatten()[0].item() for p in params]
-    q.put((rank, loss.item(), g.numpy(), ok_gather, avg))
+    extra = {}
+    # a second call without a fresh backward and with the gradients kept (zero_grad(set_to_none=False) / accumulation):
+    # nothing aliases the buckets, so this must simply average the (already equal) values again
+    red()
+    extra["again"] = [p.grad.flatten()[0].item() for p in params]
+    # accumulation across two "backward passes": .grad += new local gradient, then one exchange
+    for i, p in enumerate(params):
+        p.grad.zero_()
+        p.grad += float(rank + 1) * (i + 1)
+        p.grad += float(rank + 1) * (i + 1)
+    red()
+    extra["accum"] = [p.grad.flatten()[0].item() for p in params]
+    # the in-backward protocol: gradients appear in backward order; complete leading buckets go out at once
+    red2 = GradAllReduce(params, bucket_bytes=32)
+    grads = {}
+    order = list(reversed(params))
+    early = []
+    for i, p in enumerate(order):
+        grads[id(p)] = torch.full_like(p, float(rank + 1) * (10 + i))
+        red2.ready(grads)
+        early.append(red2.launched_early)
+    red2.finish(grads)
+    extra["hook"] = [grads[id(p)].flatten()[0].item() for p in order]
+    extra["early"] = early
+    extra["nbuckets"] = len(red2.buckets)
+    # a parameter that received no gradient this step is reduced as zeros and left alone
+    red3 = GradAllReduce(params, bucket_bytes=1 << 20)
+    g3 = {id(params[0]): torch.full_like(params[0], float(rank + 1))}
+    red3.ready(g3)
+    red3.finish(g3)
+    extra["partial"] = (g3[id(params[0])].flatten()[0].item(), red3.launched_early, len(g3))
+    # Utilities.reduce_tensor (SimCLR/Utilities.py:30-34): mean over ranks, argument untouched
+    t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
+    r = Utilities.reduce_tensor(t, world)
+    extra["reduce_tensor"] = (r.tolist(), t.tolist())
+    # the prefetched embedding gather (CPU tensors: no side stream, same protocol)
+    hh = H1[rank * b:(rank + 1) * b].clone()
+    D.prefetch_embedding(hh, lambda v: (O.l2_normalize(v), torch.ones(v.shape[0])), world)
+    got = D.take_prefetched(hh.data, world)
+    extra["prefetch"] = bool(got is not None and torch.allclose(got[2], O.l2_normalize(H1)) and D.take_prefetched(hh.data, world) is None)
+    hh2 = hh.clone()
+    D.prefetch_embedding(hh2, lambda v: (O.l2_normalize(v), torch.ones(v.shape[0])), world)
+    hh2.add_(1.0)   # modified in place after the prefetch: the stale gather must not be used
+    extra["prefetch_stale"] = D.take_prefetched(hh2.data, world) is None
+    D.drop_prefetched()
+    q.put((rank, loss.item(), g.numpy(), ok_gather, avg, extra))
     dist.destroy_process_group()
 
 
@@ -49,9 +98,16 @@ def test_two_rank_gloo(golden_dir, world):
     res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
     G = np.load(os.path.join(golden_dir, "ntxent_gloo.npz"))
-    for r, loss, g, ok, avg in res:
+    for r, loss, g, ok, avg, extra in res:
         assert ok
         np.testing.assert_allclose(loss, G[f"w{world}_loss"][r], rtol=1e-6)
         np.testing.assert_allclose(g, G[f"w{world}_dh2"][r], rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(avg, [1.5, 3.0, 4.5])
+        np.testing.assert_allclose(extra["again"], [1.5, 3.0, 4.5])
+        np.testing.assert_allclose(extra["accum"], [3.0, 6.0, 9.0])
+        np.testing.assert_allclose(extra["hook"], [1.5 * 10, 1.5 * 11, 1.5 * 12])
+        assert extra["nbuckets"] == 2 and extra["early"] == [1, 1, 2], extra   # bucket 0 = the last parameter, bucket 1 = the other two
+        assert extra["partial"] == (1.5, 0, 1)
+        assert extra["reduce_tensor"] == ([1.5, 15.0], [float(r + 1), 10.0 * (r + 1)])
+        assert extra["prefetch"] and extra["prefetch_stale"]
     np.testing.assert_allclose(np.mean([x[1] for x in res]), G[f"w{world}_global_loss"], rtol=1e-6)

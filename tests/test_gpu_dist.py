@@ -1,6 +1,9 @@
-"""Two ranks sharing one MI355X over gloo (RCCL needs one GPU per rank): SyncBatchNorm statistics,
-the packed embedding all-gather and the rank-offset labels must reproduce the single-process result on
-the concatenated batch (the reference's multi-rank semantics, Objective.py:51-58)."""
+"""Two ranks on the N > 1 code path: SyncBatchNorm statistics (the projection-shortcut pair in one exchange), the
+embedding all-gather prefetched on the side stream by SimCLR_Module.forward, the rank-offset labels and the gradient
+buckets all-reduced from inside the backward pass must reproduce the single-process result on the concatenated
+batch (the reference's multi-rank semantics, Objective.py:51-58).
+* test_two_ranks_match_single_process: both ranks share ONE MI355X over gloo (runs on the one-GPU box);
+* test_two_ranks_rccl: one GPU per rank over the 'nccl' (= RCCL) backend; skipped where fewer than two GPUs exist."""
 import os
 import sys
 
@@ -38,41 +41,74 @@ def _inputs(B):
     return (torch.randint(0, 256, (B, 3, 32, 32), generator=g).float(), torch.randint(0, 256, (B, 3, 32, 32), generator=g).float())
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     _paths()
     import Objective
     from maai_hip import engine
-    from maai_hip.dist import GradAllReduce
+    from maai_hip import dist as D
+    from maai_hip.dist import GradReducer
     engine.set_precision("fp32")
     B = 16
     b = B // world
     x1, x2 = _inputs(B)
     m = _model(world, b)
     sl = slice(rank * b, (rank + 1) * b)
+    # step A: no gradient exchange -> the local gradient of this rank
     with torch.no_grad():
         h1 = m.forward_tensor(x1[sl].cuda())
     h2 = m.forward_tensor(x2[sl].cuda())
     loss, logits, labels = Objective.contrastive_loss(h1.data, h2, temperature=0.5, local_rank=rank, world_size=world, device="cuda")
     loss.backward()
-    g_local = m.f.conv1.weight.grad.clone()
-    GradAllReduce(list(m.parameters()))()
     torch.cuda.synchronize()
-    q.put((rank, loss.item(), h2.detach().cpu().numpy(), logits.cpu().numpy(), labels.argmax(1).cpu().numpy(),
-           m.f.bn1.running_mean.cpu().numpy(), g_local.cpu().numpy(), m.f.conv1.weight.grad.cpu().numpy()))
+    g_local = {n: p.grad.clone() for n, p in m.named_parameters() if n in ("f.conv1.weight", "g.layers.2.bias", "f.layer3.0.bn2.weight")}
+    rm = m.f.bn1.running_mean.cpu().numpy()
+    hits_a = D.STATS["prefetch_hits"]
+    # step B, same weights and inputs: gradient buckets go out from inside the backward pass (engine hook)
+    m.zero_grad(set_to_none=True)
+    red = GradReducer(list(m.parameters()), bucket_bytes=16 << 20)
+    engine.set_grad_hook(red)
+    with torch.no_grad():
+        h1b = m.forward_tensor(x1[sl].cuda())
+    h2b = m.forward_tensor(x2[sl].cuda())
+    lossb, _, _ = Objective.contrastive_loss(h1b.data, h2b, temperature=0.5, local_rank=rank, world_size=world, device="cuda")
+    lossb.backward()
+    torch.cuda.synchronize()
+    engine.set_grad_hook(None)
+    g_avg = {n: p.grad.clone() for n, p in m.named_parameters() if n in g_local}
+    stats = dict(D.STATS, launched_early=red.launched_early, nbuckets=len(red.buckets), hits_a=hits_a)
+    q.put((rank, loss.item(), h2.detach().cpu().numpy(), logits.cpu().numpy(), labels.argmax(1).cpu().numpy(), rm,
+           {n: v.cpu().numpy() for n, v in g_local.items()}, {n: v.cpu().numpy() for n, v in g_avg.items()}, stats))
     dist.destroy_process_group()
+
+
+def test_two_ranks_rccl():
+    """The same protocol with one MI355X per rank over RCCL (backend 'nccl')."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
+    _run_two_ranks("nccl", 29743)
 
 
 def test_two_ranks_match_single_process():
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device")
+    _run_two_ranks("gloo", 29741)
+
+
+def _run_two_ranks(backend, port):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, 29741, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
@@ -90,7 +126,7 @@ def test_two_ranks_match_single_process():
         loss, logits, _ = Objective.contrastive_loss(h1, h2, temperature=0.5)
     engine.set_precision("bf16")
     b = B // world
-    for r, l, z, lg, lab, rm, gl, ga in res:
+    for r, l, z, lg, lab, rm, gl, ga, st in res:
         # SyncBN statistics are global -> per-rank embeddings equal the big-batch ones
         np.testing.assert_allclose(z, h2[r * b:(r + 1) * b].cpu().numpy(), rtol=2e-3, atol=2e-4)
         np.testing.assert_allclose(lg, logits[r * b:(r + 1) * b].cpu().numpy(), rtol=2e-3, atol=2e-3)
@@ -98,7 +134,14 @@ def test_two_ranks_match_single_process():
         np.testing.assert_allclose(rm, m.f.bn1.running_mean.cpu().numpy(), rtol=1e-4, atol=1e-5)
     # mean over ranks of the per-rank loss == single-process loss on the global batch
     np.testing.assert_allclose(np.mean([x[1] for x in res]), loss.item(), rtol=1e-4)
-    # gradient all-reduce: both ranks hold the average of the local gradients
-    avg = (res[0][6] + res[1][6]) / 2
+    # gradient exchange from inside the backward pass: both ranks hold the average of the two local gradients
+    for name in res[0][6]:
+        avg = (res[0][6][name] + res[1][6][name]) / 2
+        for x in res:
+            np.testing.assert_allclose(x[7][name], avg, rtol=2e-5, atol=1e-6 * float(np.abs(avg).max()))
     for x in res:
-        np.testing.assert_allclose(x[7], avg, rtol=1e-5, atol=1e-7)
+        st = x[8]
+        # every embedding gather was started by the forward pass on the side stream and picked up by the loss
+        assert st["prefetch_started"] == 4 and st["prefetch_hits"] == 4 and st["hits_a"] == 2, st
+        # the head's bucket(s) went out before the backbone was differentiated
+        assert st["nbuckets"] >= 3 and st["launched_early"] >= 1 and st["buckets_early"] + st["buckets_late"] == st["nbuckets"], st
