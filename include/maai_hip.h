@@ -245,7 +245,8 @@ int maai_cast_to_f32(const void* src, float* dst, long long n, int dtype, void* 
  * normalize == 0 copies. */
 int maai_ntxent_normalize(const float* h, float* z, float* inv_norm, int B, int d, int normalize, void* stream);
 /* loss (1 float, zeroed by callee), logits_ab [B,N] (= z1 Z2^T / tau), lse [2][B]
- * (row log-sum-exp of [ab,aa] and [ba,bb] with the -1e9 self mask). d % 16 == 0, d <= 512. */
+ * (row log-sum-exp of [ab,aa] and [ba,bb] with the -1e9 self mask). d % 16 == 0, d <= 496 (the
+ * backward pass keeps 16 x (d + 4) + 64 x d floats in LDS: 160 KiB). */
 int maai_ntxent_fwd(const float* z1, const float* z2, const float* Z1, const float* Z2, float* loss, float* logits_ab,
                     float* lse, int B, int N, int d, float temperature, int row_offset, void* stream);
 /* gradients of loss*gloss wrt z2 (always) and z1 (nullable).  local_in_gathered != 0
@@ -294,6 +295,30 @@ typedef struct {
 } maai_adam_slot;
 int maai_adam_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
                          double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
+
+/* LARC (Model_Util.py:80-83: `--optimizer lars` = apex.parallel.LARC around Adam; Apex's published algorithm,
+ * trust_coefficient 0.02, clip mode — parity UNPINNED, Apex cannot be installed here).  slots / block maps as in
+ * maai_adam_step_multi (m and v unused).  maai_multi_sqnorm: norms[2*s] = ||p_s||^2, norms[2*s+1] = ||g_s||^2 (fp64,
+ * zeroed by the callee) for every tensor in ONE launch.  maai_larc_scale: for every tensor with non-zero norms,
+ * g <- (g + wd*p) * rate, rate = trust*||p|| / (||g|| + wd*||p|| + eps), clipped to min(rate/lr, 1) when clip. */
+int maai_multi_sqnorm(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                      int nslots, double* norms, void* stream);
+int maai_larc_scale(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                    const double* norms, float trust_coefficient, float lr, float weight_decay, float eps, int clip,
+                    void* stream);
+
+/* ------------------------------------------------------------------------
+ * Linear probe on frozen features (Representation_Evaluation.py:621-666): the logits are a 1x1 convolution
+ * (maai_conv2d_igemm, fp32); this is nn.CrossEntropyLoss on them — mean over the batch of
+ * logsumexp(logits[b,:C]) - logits[b,label[b]], class-index targets (int64) — and its gradient
+ * dlogits[b,c] = (softmax - onehot) * gloss / B.  logits / dlogits are [B][ld] with ld >= C (columns C..ld-1 are
+ * padding of the GEMM's 64-column granularity: ignored, gradient 0).  loss (1 float) is zeroed by the callee;
+ * lse [B] is kept for the backward pass.
+ * ------------------------------------------------------------------------ */
+int maai_softmax_ce_fwd(const float* logits, const long long* labels, float* loss, float* lse, int B, int C, int ld,
+                        void* stream);
+int maai_softmax_ce_bwd(const float* logits, const long long* labels, const float* lse, const float* gloss, float* dlogits,
+                        int B, int C, int ld, void* stream);
 
 /* ------------------------------------------------------------------------
  * Two-view augmentation replacing NVIDIA_DALI_Pipelines.py:444-480 for the

@@ -1,14 +1,31 @@
-"""Reference-compatible SimCLR/MLR/multivariateLogisticRegression.py (:6-13).
-One nn.Linear used only by the linear-probe driver — outside the hot path
-(SURVEY §2.1 marks it out of scope), kept as plain torch so that
-Representation_Evaluation.py imports resolve."""
+"""Drop-in for the reference's SimCLR/MLR/multivariateLogisticRegression.py (:6-13): the linear-probe classifier of
+Representation_Evaluation.py:598-712.  ``self.linear`` stays an ``nn.Linear`` (same state_dict keys); its forward and
+backward run on the HIP kernels (maai_hip.probe: implicit-GEMM logits in exact fp32) whenever the features live on a
+HIP device.  ``HipCrossEntropyLoss`` is the matching criterion on the library's softmax-CE kernel."""
+import os
+import sys
+
 import torch.nn as nn
+
+try:
+    import maai_hip  # noqa: F401
+except ImportError:
+    _h = os.path.dirname(os.path.abspath(__file__))
+    for _c in (os.environ.get("MAAI_AMD_HOME", ""), os.path.join(_h, "..", ".."), os.path.join(_h, "..", "..", "multimodal-active-ai_amd")):
+        if _c and os.path.isdir(os.path.join(_c, "maai_hip")):
+            sys.path.insert(0, os.path.abspath(_c))
+            break
+    import maai_hip  # noqa: F401
+from maai_hip import probe as _probe
 
 
 class LogisticRegression(nn.Module):
-    def __init__(self, input_dim, output_dim):
+    def __init__(self, input_size, num_classes):
         super().__init__()
-        self.linear = nn.Linear(input_dim, output_dim)
+        self.linear = nn.Linear(input_size, num_classes)
 
     def forward(self, x):
-        return self.linear(x)
+        return _probe.linear(x, self.linear.weight, self.linear.bias)
+
+
+HipCrossEntropyLoss = _probe.CrossEntropyLoss

@@ -118,6 +118,13 @@ def _synthetic(n, seed0):
     return [(seed0 + i, 480 + 16 * (i % 5), 640 - 32 * (i % 3)) for i in range(n)], [i % 1000 for i in range(n)]
 
 
+def _missing(kind, path):
+    """DALI's readers fail on a dataset path that does not exist; so do these.  Random images are produced ONLY on
+    request (MAAI_SYNTHETIC_DATA=<count>): a mistyped or unmounted path must never train or evaluate on noise."""
+    return FileNotFoundError("%s: file_root %r is not a directory (set MAAI_SYNTHETIC_DATA=<images> to run on synthetic "
+                             "images on purpose)" % (kind, path))
+
+
 class COCOReader(_Reader):
     reader_name = "COCOReader"
 
@@ -127,9 +134,11 @@ class COCOReader(_Reader):
 
     def _list(self):
         syn = int(os.environ.get("MAAI_SYNTHETIC_DATA", "0"))
-        if syn or not os.path.isdir(self.file_root):
-            self.files, self.labels = _synthetic(syn or 4 * self.batch_size * self.num_shards, 1000)
+        if syn:
+            self.files, self.labels = _synthetic(syn, 1000)
             return
+        if not os.path.isdir(self.file_root):
+            raise _missing("COCOReader", self.file_root)
         names = None
         if os.path.isfile(self.annotations_file):
             with open(self.annotations_file) as fh:
@@ -152,9 +161,11 @@ class ImagenetReader(_Reader):
 
     def _list(self):
         syn = int(os.environ.get("MAAI_SYNTHETIC_DATA", "0"))
-        if syn or not os.path.isdir(self.file_root):
-            self.files, self.labels = _synthetic(syn or 4 * self.batch_size * self.num_shards, 2000)
+        if syn:
+            self.files, self.labels = _synthetic(syn, 2000)
             return
+        if not os.path.isdir(self.file_root):
+            raise _missing("ImagenetReader", self.file_root)
         classes = sorted(d for d in os.listdir(self.file_root) if os.path.isdir(os.path.join(self.file_root, d)))
         for ci, c in enumerate(classes):                           # ops.FileReader: one label per sub-directory
             for f in sorted(os.listdir(os.path.join(self.file_root, c))):

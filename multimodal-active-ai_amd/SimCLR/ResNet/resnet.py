@@ -38,10 +38,12 @@ def conv1x1(in_planes, out_planes, stride=1):
 
 
 class _Block(nn.Module):
-    """Parameter container; the engine walks .conv*/.bn*/.downsample/.stride."""
+    """Parameter container; ``ResNet.forward`` hands the whole stack to the engine, which walks
+    .conv*/.bn*/.downsample/.stride.  Called on its own (a consumer iterating ``layerN``), a block runs as one
+    engine call: NCHW fp32 in, NCHW fp32 out, differentiable."""
 
     def forward(self, x):
-        raise NotImplementedError("residual blocks are executed by ResNet.forward on the HIP engine, not one by one")
+        return _engine.block_forward(self, x)
 
 
 class BasicBlock(_Block):

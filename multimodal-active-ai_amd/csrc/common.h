@@ -35,6 +35,18 @@ extern "C" void maai_set_error(const char* msg);
     }                                                         \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember, per device, the largest
+// size already granted (table: 64 ints, zero-initialised, one per kernel instantiation).
+static inline void maai_ensure_lds(const void* fn, int lds, int* table) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int& have = table[dev & 63];
+  if (lds > have) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    have = lds;
+  }
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN-preserving: a plain __bf16 cast, which hipcc lowers to v_cvt_pk_bf16_f32

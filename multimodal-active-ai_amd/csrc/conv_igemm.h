@@ -837,12 +837,8 @@ static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
     maai_set_error("conv2d_igemm: the transformed-operand tables do not fit in LDS for this many input channels");
     return MAAI_ERR_UNSUPPORTED;
   }
-  static int attr_lds = -1;
-  if (lds > attr_lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_lds = lds;
-  }
+  static int attr_lds[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>), lds, attr_lds);
   const long long grid = (long long)a.nMB * a.nNB;
   hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();

@@ -455,12 +455,9 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   a.pix_per_split = steps_per * PK;
   const int ny = (a.M + a.pix_per_split - 1) / a.pix_per_split;
   const int ny8 = (ny + 7) / 8 * 8;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
+  static int attr_a[64] = {0}, attr_b[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), lds, attr_a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), lds, attr_b);
   if (a.xs)
     hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
   else
@@ -718,12 +715,9 @@ static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
   a.per_split = (a.npatch + split - 1) / split;
   split = (a.npatch + a.per_split - 1) / a.per_split;
   constexpr int lds = 8 * 16 * 128 + 10 * 24 * 128;  // 16 KB + 30 KB
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
+  static int attr_a[64] = {0}, attr_b[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false>), lds, attr_a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true>), lds, attr_b);
   if (a.xs)
     hipLaunchKernelGGL(wgrad3x3_patch_kernel<true>, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
   else
@@ -765,12 +759,9 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
   const int steps_per = (int)((ksteps + split - 1) / split);
   a.pix_per_split = steps_per * PK;
   const int ny = (a.M + a.pix_per_split - 1) / a.pix_per_split;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
+  static int attr_a[64] = {0}, attr_b[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, false>), lds, attr_a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, true>), lds, attr_b);
   if (a.xs)
     hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, true>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
   else

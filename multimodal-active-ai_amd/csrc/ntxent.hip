@@ -204,7 +204,7 @@ extern "C" int maai_ntxent_fwd(const float* z1, const float* z2, const float* Z1
                                float* logits_ab, float* lse, int B, int N, int d, float temperature, int row_offset,
                                void* stream) {
   MAAI_CHECK_ARG(z1 && z2 && Z1 && Z2 && loss && logits_ab && lse, "ntxent_fwd: null pointer");
-  MAAI_CHECK_ARG(B > 0 && N >= B && d > 0 && d % 16 == 0 && d <= 512, "ntxent_fwd: need N >= B, d % 16 == 0, d <= 512");
+  MAAI_CHECK_ARG(B > 0 && N >= B && d > 0 && d % 16 == 0 && d <= 496, "ntxent_fwd: need N >= B, d % 16 == 0, d <= 496 (the backward pass holds 16 x (d + 4) + 64 x d floats in the 160 KiB of LDS)");
   MAAI_CHECK_ARG(row_offset >= 0 && row_offset + B <= N && temperature > 0.f, "ntxent_fwd: bad row_offset / temperature");
   const size_t lds = (16 * (d + 4) + 4 * 16 * 3) * sizeof(float);
   hipLaunchKernelGGL(ntxent_fwd_kernel, dim3((B + 15) / 16, 2), dim3(256), lds, ST(stream), z1, z2, Z1, Z2, logits_ab, lse, B, N,
@@ -305,11 +305,8 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(NtxBwdArgs a) {
 
 static int launch_bwd(const NtxBwdArgs& a, hipStream_t st) {
   const size_t lds = (16 * (a.d + 4) + 4 * 16 * a.d) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static int attr[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&ntxent_bwd_kernel), (int)lds, attr);
   hipLaunchKernelGGL(ntxent_bwd_kernel, dim3((a.tcnt + 15) / 16), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
@@ -319,7 +316,7 @@ extern "C" int maai_ntxent_bwd(const float* z1, const float* z2, const float* Z1
                                const float* gloss, float* dz1, float* dz2, int B, int N, int d, float temperature,
                                int row_offset, int local_in_gathered, void* stream) {
   MAAI_CHECK_ARG(z1 && z2 && Z1 && Z2 && lse && dz2, "ntxent_bwd: null pointer");
-  MAAI_CHECK_ARG(B > 0 && N >= B && d > 0 && d % 16 == 0 && d <= 512, "ntxent_bwd: need N >= B, d % 16 == 0, d <= 512");
+  MAAI_CHECK_ARG(B > 0 && N >= B && d > 0 && d % 16 == 0 && d <= 496, "ntxent_bwd: need N >= B, d % 16 == 0, d <= 496 (16 x (d + 4) + 64 x d floats must fit the 160 KiB of LDS)");
   MAAI_CHECK_ARG(row_offset >= 0 && row_offset + B <= N && temperature > 0.f, "ntxent_bwd: bad row_offset / temperature");
   hipStream_t st = ST(stream);
   const float* lse_a = lse;

@@ -76,6 +76,10 @@ SIGNATURES = {
     "maai_ntxent_normalize_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_d, c_d, c_d, c_d, c_i, c_f, c_p]),
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
+    "maai_multi_sqnorm": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "maai_larc_scale": (c_i, [c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
+    "maai_softmax_ce_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "maai_softmax_ce_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "maai_augment_view_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maai_foveate_views_u8": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "maai_augment_params": (c_i, [c_p, c_i, c_i, c_i, c_ull, c_i, c_f, c_f, c_f, c_f, c_f, c_p]),

@@ -234,6 +234,15 @@ def _fusable(conv, form, keep=True):
             and conv.in_channels <= lim and conv.out_channels >= 4 * conv.in_channels)
 
 
+def _is_frozen_bn(bn):
+    return (not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm)
+            and all(hasattr(bn, a) for a in ("weight", "bias", "running_mean", "running_var")))
+
+
+def _bn_eps(bn):
+    return float(getattr(bn, "eps", 1e-5))
+
+
 def _sync_world(bn):
     if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized():
         return dist.get_world_size()
@@ -429,7 +438,11 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     stride, pad = conv.stride[0], conv.padding[0]
     if wq is None:
         wq = w_fwd(conv.weight, dtype)
-    training = bn.training or (bn.running_mean is None)
+    # norm layers that are not torch BatchNorm modules but carry (weight, bias, running_mean, running_var) — the
+    # FrozenBatchNorm2d the DETR backbone builds the ResNet with (detr_CLA/models/backbone.py:35-67, eps 1e-5 inside its
+    # forward) — are frozen statistics whatever the module's train()/eval() flag says: folded scale / shift
+    frozen = _is_frozen_bn(bn)
+    training = False if frozen else (bn.training or (bn.running_mean is None))
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
     fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
@@ -482,7 +495,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             mom = 0.0
         mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
-        scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, _bn_eps(bn))
         if eval_fused:
             # inference with frozen statistics: normalise (+ shortcut) + activate in the convolution's own epilogue,
             # one launch per unit and no raw conv output in HBM (MAAI_EPI_BN_ACT on any kernel size)
@@ -687,7 +700,7 @@ def _unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums=None):
     else:
         # frozen statistics: y -> y*scale + shift is a per-channel affine map
         sums = reduce(bn.running_mean)
-        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        invstd = torch.rsqrt(bn.running_var + _bn_eps(bn))
         dbeta = sums[:sums.numel() // 2].float()
         dgamma = (sums[sums.numel() // 2:].float() * invstd)
         k1, k2, k3 = rec.scale, torch.zeros_like(rec.scale), torch.zeros_like(rec.scale)
@@ -878,12 +891,14 @@ def backbone_fwd(resnet, x, dtype, keep):
     return out, tape
 
 
-def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
+def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=True):
     """Backward of one residual block.  ``dout`` must already carry the block output's ReLU mask; the
     returned gradient wrt the block input carries the block input's mask (folded into the last epilogue).
     ``dout`` may be overwritten (identity shortcut: the conv1 data gradient is accumulated into it).
     ``prev`` = record of the unit that produced the block input, ``presums`` = the last unit's BN-backward sums
-    when the producer of ``dout`` reduced them.  Returns (dx, sums for ``prev`` or None)."""
+    when the producer of ``dout`` reduced them.  ``mask_input=False`` (a block run on its own, whose input is an
+    arbitrary tensor): the returned gradient is the plain d/dx.  Returns (dx, sums for ``prev`` or None)."""
+    in_mask = (lambda: r1.x) if mask_input else (lambda: None)
     _, r1, r2, r3, rd = entry
     dyd = None
     if rd is not None and _DUAL_BN["enabled"] and not r3.fused and not rd.fused:
@@ -912,17 +927,17 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None):
                 raise MaaiError("block_bwd: the two passes of a strided shortcut must both reduce or both not")
         else:
             # (a stride-1 shortcut's pass rewrites — and masks — every pixel: the first pass then needs no mask)
-            dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=r1.x if strided else None, presums=s)
+            dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=in_mask() if strided else None, presums=s)
             if prev is not None:
                 dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
             else:
-                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=r1.x, dy=dyd)
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=in_mask(), dy=dyd)
     else:
         # identity shortcut: dx = dout + dgrad(conv1), accumulated in place in the conv epilogue
         if prev is not None:
             dx, sp = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, below=prev, presums=s)
         else:
-            dx, sp = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, relu_mask=r1.x, presums=s)
+            dx, sp = unit_bwd(r1, d, grads, dtype, dx_out=dout, accumulate=True, relu_mask=in_mask(), presums=s)
     return dx, sp
 
 
@@ -1108,6 +1123,46 @@ class _BackboneFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_stream(_side_stream())
         ctx.tape = None
         return (None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+
+
+class _BlockFn(torch.autograd.Function):
+    """One residual block on its own (consumers that walk ``layerN`` sub-modules, e.g. an intermediate-layer getter
+    over the backbone): NCHW fp32 in and out, the reference's BasicBlock / Bottleneck.forward contract
+    (resnet.py:59-77, 113-135)."""
+
+    @staticmethod
+    def forward(ctx, x, blk, keep, need_dx, *params):
+        dtype = compute_dtype()
+        b, c, h, w = x.shape
+        xin = K.nchw_to_nhwc(x.contiguous().float(), c, dtype)
+        out, recs, _, _ = _block_fwd(blk, xin, dtype, keep)
+        ctx.recs, ctx.dtype, ctx.params, ctx.keep, ctx.need_dx, ctx.cin = recs, dtype, params, keep, need_dx, c
+        return K.nhwc_to_nchw(out, out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.keep:
+            raise MaaiError("backward through a forward that ran without gradients")
+        grads = {}
+        r3 = ctx.recs[2]
+        d = K.nchw_to_nhwc(dout.contiguous().float(), dout.shape[1], ctx.dtype)
+        d = relu_mask_grad(d, r3.out)
+        dx, _ = block_bwd(("block",) + ctx.recs, d, grads, ctx.dtype, prev=None, mask_input=False)
+        ctx.recs = None
+        gx = K.nhwc_to_nchw(dx, ctx.cin) if ctx.need_dx else None
+        return (gx, None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
+
+
+def block_forward(blk, x):
+    """``blk(x)`` for one BasicBlock / Bottleneck of this package's ResNet on the HIP engine."""
+    _need_gpu_module(blk)
+    if not x.is_cuda:
+        raise MaaiError("the HIP path needs tensors on a HIP device (got %s); there is no CPU fallback" % x.device)
+    if x.dim() != 4 or x.shape[1] != blk.conv1.in_channels:
+        raise MaaiError("block: expected NCHW input with %d channels, got %s" % (blk.conv1.in_channels, tuple(x.shape)))
+    params = trainable_params(blk)
+    keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return _BlockFn.apply(x, blk, keep, x.requires_grad, *params)
 
 
 class _HeadFn(torch.autograd.Function):

@@ -725,6 +725,73 @@ class AdamMulti(object):
               "maai_adam_step_multi")
 
 
+class LarcMulti(object):
+    """||w||, ||g|| of every tensor in one launch (maai_multi_sqnorm) and the LARC rescaling of all gradients in a
+    second (maai_larc_scale).  Block map built once from the sizes; the slot table is re-uploaded per step (gradient
+    tensors are new every step)."""
+    CHUNK = 2048
+
+    def __init__(self, params):
+        import numpy as np
+        self.params = list(params)
+        _gpu(*self.params)
+        dev = self.params[0].device
+        slot, first = [], []
+        for i, p in enumerate(self.params):
+            nb = (p.numel() + self.CHUNK - 1) // self.CHUNK
+            slot.append(np.full(nb, i, dtype=np.int32))
+            first.append(np.arange(nb, dtype=np.int64) * self.CHUNK)
+        self.block_slot = torch.from_numpy(np.concatenate(slot)).to(dev)
+        self.block_first = torch.from_numpy(np.concatenate(first)).to(dev)
+        self.nblocks = int(self.block_slot.numel())
+        self.table = np.zeros((len(self.params), 5), dtype=np.int64)
+        for i, p in enumerate(self.params):
+            self.table[i, 0], self.table[i, 4] = p.data_ptr(), p.numel()
+        self.table_dev = torch.empty((len(self.params), 5), dtype=torch.int64, device=dev)
+        self.norms = torch.empty((len(self.params), 2), dtype=torch.float64, device=dev)
+
+    def _upload(self, grads):
+        _gpu(*grads)
+        for i, g in enumerate(grads):
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.table[i, 4]:
+                raise MaaiError("LARC: gradients must be contiguous fp32 tensors of the parameter's size")
+            self.table[i, 1] = g.data_ptr()
+        self.table_dev.copy_(torch.from_numpy(self.table), non_blocking=False)
+
+    def sqnorms(self, grads):
+        """[n,2] fp64: ||p||^2, ||g||^2 per tensor"""
+        self._upload(grads)
+        check(lib().maai_multi_sqnorm(_p(self.table_dev), _p(self.block_slot), _p(self.block_first), self.nblocks, len(self.params),
+                                      _p(self.norms), _stream()), "maai_multi_sqnorm")
+        return self.norms
+
+    def scale(self, trust, lr, weight_decay, eps, clip):
+        """in place on the gradients given to the last sqnorms() call"""
+        check(lib().maai_larc_scale(_p(self.table_dev), _p(self.block_slot), _p(self.block_first), self.nblocks, _p(self.norms),
+                                    float(trust), float(lr), float(weight_decay), float(eps), 1 if clip else 0, _stream()),
+              "maai_larc_scale")
+
+
+def softmax_ce_fwd(logits, labels, ncls):
+    """mean cross-entropy over the first ``ncls`` columns of logits [B, ld] (fp32), labels int64 [B] -> (loss 0-d, lse [B])"""
+    _gpu(logits, labels)
+    if logits.dtype != torch.float32 or labels.dtype != torch.int64 or logits.dim() != 2 or labels.shape != (logits.shape[0],):
+        raise MaaiError("softmax_ce: logits must be fp32 [B,ld] and labels int64 [B]")
+    b, ld = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    lse = torch.empty(b, dtype=torch.float32, device=logits.device)
+    check(lib().maai_softmax_ce_fwd(_p(logits), _p(labels), _p(loss), _p(lse), b, int(ncls), ld, _stream()), "maai_softmax_ce_fwd")
+    return loss, lse
+
+
+def softmax_ce_bwd(logits, labels, lse, gloss, ncls):
+    _gpu(logits, labels, lse, gloss)
+    b, ld = logits.shape
+    d = torch.empty_like(logits)
+    check(lib().maai_softmax_ce_bwd(_p(logits), _p(labels), _p(lse), _p(gloss), _p(d), b, int(ncls), ld, _stream()), "maai_softmax_ce_bwd")
+    return d
+
+
 def sgd_step(p, g, mom, lr, momentum, weight_decay, first_step):
     _gpu(p, g, mom)
     check(lib().maai_sgd_step(_p(p), _p(g), _p(mom), p.numel(), float(lr), float(momentum), float(weight_decay),

@@ -5,6 +5,7 @@ behave like torch.optim.Adam / SGD."""
 import torch
 
 from . import kernels as K
+from ._lib import MaaiError
 from .engine import bump_weight_epoch
 
 
@@ -117,22 +118,31 @@ class LARC(object):
         self.optim.zero_grad(*a, **k)
 
     def step(self):
+        """Two launches per parameter group (all norms; all rescalings) around the wrapped optimiser's step; the
+        group's own weight decay is folded into the gradient here and switched off for the inner step, as Apex does."""
         with torch.no_grad():
             saved = []
-            for group in self.optim.param_groups:
+            for gi, group in enumerate(self.optim.param_groups):
                 wd = group.get("weight_decay", 0.0)
                 saved.append(wd)
                 group["weight_decay"] = 0.0
-                for p in group["params"]:
-                    if p.grad is None:
-                        continue
-                    pn, gn = torch.norm(p), torch.norm(p.grad)
-                    rate = self.trust_coefficient * pn / (gn + pn * wd + self.eps)
-                    if self.clip:
-                        rate = torch.clamp(rate / group["lr"], max=1.0)
-                    rate = torch.where((pn > 0) & (gn > 0), rate, torch.ones_like(rate))
-                    p.grad.add_(p, alpha=wd)
-                    p.grad.mul_(rate)
+                ps = [p for p in group["params"] if p.grad is not None]
+                if not ps:
+                    continue
+                if not all(p.is_cuda for p in ps):
+                    raise MaaiError("LARC runs on the HIP kernels: parameters must live on a HIP device (no CPU fallback)")
+                key = tuple(id(p) for p in ps)
+                cache = self.__dict__.setdefault("_multi", {})
+                if cache.get(gi, (None, None))[0] != key:
+                    cache[gi] = (key, K.LarcMulti(ps))
+                multi = cache[gi][1]
+                grads = []
+                for p in ps:
+                    if not p.grad.is_contiguous():
+                        p.grad = p.grad.contiguous()
+                    grads.append(p.grad)
+                multi.sqnorms(grads)
+                multi.scale(self.trust_coefficient, group["lr"], wd, self.eps, self.clip)
         self.optim.step()
         for group, wd in zip(self.optim.param_groups, saved):
             group["weight_decay"] = wd

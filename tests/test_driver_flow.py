@@ -15,9 +15,11 @@ for d in (SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"), os.path.jo
 
 
 def _pipes(NDP, batch, device_id=0, world=1, shard=0):
+    os.environ["MAAI_SYNTHETIC_DATA"] = str(4 * batch * world)    # synthetic images on purpose (no dataset in this image)
     pipe1 = NDP.ImagenetReader(batch_size=batch, num_threads=2, device_id=device_id, file_root="/nonexistent/train",
                                shard_id=shard, num_shards=world, dali_cpu=False)
     pipe1.build()
+    os.environ.pop("MAAI_SYNTHETIC_DATA", None)
     images = NDP.ImageCollector()
     fixation, noise = NDP.FixationCommand(batch), NDP.NoiseCommand(batch)
     color, grid = NDP.ColorCommand(batch), NDP.GridMaskCommand(batch)
@@ -61,6 +63,13 @@ def test_reader_and_command_host_logic(tmp_path):
         assert torch.equal(again.images[:, :400, :500], imgs.images[:, :400, :500]) or True  # flips are random per run
     finally:
         os.environ.pop("MAAI_SYNTHETIC_DATA", None)
+    # a missing dataset path fails like DALI's readers do (never a silent switch to random images)
+    for reader in (NDP.COCOReader(batch_size=8, num_threads=1, device_id=0, file_root="/nonexistent/coco", annotations_file="/nonexistent.json",
+                                  shard_id=0, num_shards=1, dali_cpu=True),
+                   NDP.ImagenetReader(batch_size=8, num_threads=1, device_id=0, file_root="/nonexistent/train", shard_id=0, num_shards=1,
+                                      dali_cpu=True)):
+        with pytest.raises(FileNotFoundError):
+            reader.build()
     # a real directory of .npy / PNG files, ImageNet layout (one sub-directory per class)
     from PIL import Image
     for c in ("n01", "n02"):

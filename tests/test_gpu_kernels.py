@@ -896,3 +896,68 @@ def test_store_reduce_sum_increment_completes_the_sums(K, dtype):
     wf, yf = want.double().reshape(-1, c), ylow.double().reshape(-1, c)
     ref = torch.cat([wf.sum(0), (wf * (yf - mean.double())).sum(0)]).cpu()
     np.testing.assert_allclose(sums.numpy(), ref.numpy(), rtol=1e-4, atol=2e-3 if dtype == torch.float32 else 3e-2)
+
+
+def test_softmax_ce_kernel(K):
+    """maai_softmax_ce_fwd / _bwd against torch (nn.CrossEntropyLoss semantics: mean reduction, class-index targets),
+    including padded logit columns (ld > C) and extreme logits."""
+    g = torch.Generator().manual_seed(3)
+    for (b, c, ld) in [(8, 1000, 1024), (5, 10, 64), (33, 64, 64), (256, 1000, 1024)]:
+        logits = torch.randn(b, ld, generator=g) * 3
+        logits[0, :c] += 40.0                       # large values: the kernel subtracts the row maximum
+        logits[:, c:] = 1e6                          # padding columns must be ignored
+        labels = torch.randint(0, c, (b,), generator=g)
+        lt = logits[:, :c].clone().double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(lt, labels)
+        ref.backward()
+        loss, lse = K.softmax_ce_fwd(logits.cuda(), labels.cuda(), c)
+        d = K.softmax_ce_bwd(logits.cuda(), labels.cuda(), lse, torch.tensor([2.0]).cuda(), c)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        np.testing.assert_allclose(d[:, :c].cpu().numpy(), 2.0 * lt.grad.float().numpy(), rtol=2e-5, atol=1e-8)
+        assert float(d[:, c:].abs().max()) == 0.0 if ld > c else True
+
+
+def test_probe_linear_against_torch(K):
+    from maai_hip import probe
+    g = torch.Generator().manual_seed(4)
+    for (b, i, o) in [(8, 512, 1000), (16, 8192, 10), (3, 64, 64)]:
+        x = torch.randn(b, i, generator=g)
+        w = torch.randn(o, i, generator=g) / i ** 0.5
+        bias = torch.randn(o, generator=g)
+        dy = torch.randn(b, o, generator=g)
+        xt, wt, bt = (t.clone().double().requires_grad_(True) for t in (x, w, bias))
+        (torch.nn.functional.linear(xt, wt, bt) * dy.double()).sum().backward()
+        xg, wg, bg = (t.clone().cuda().requires_grad_(True) for t in (x, w, bias))
+        y = probe.linear(xg, wg, bg)
+        assert y.shape == (b, o)
+        (y * dy.cuda()).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), torch.nn.functional.linear(x, w, bias).numpy(), rtol=2e-5, atol=2e-5)
+        for got, ref in ((xg.grad, xt.grad), (wg.grad, wt.grad), (bg.grad, bt.grad)):
+            np.testing.assert_allclose(got.cpu().numpy(), ref.float().numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_larc_multi_tensor_kernels(K):
+    """maai_multi_sqnorm / maai_larc_scale (one launch each for all tensors) against the per-tensor formula of
+    apex.parallel.LARC as published (trust 0.02, clip); LARC parity itself stays unpinned (Apex not installable)."""
+    g = torch.Generator().manual_seed(6)
+    shapes = [(64, 3, 7, 7), (64,), (5000, 13), (1,), (2048, 3), (300,)]
+    ps = [torch.randn(s, generator=g).cuda() * (0.1 + i) for i, s in enumerate(shapes)]
+    gs = [torch.randn(s, generator=g).cuda() * 0.01 for s in shapes]
+    gs[3].zero_()                                    # a zero gradient norm: that tensor is left alone
+    multi = K.LarcMulti(ps)
+    norms = multi.sqnorms(gs).clone()
+    for i, (p, gr) in enumerate(zip(ps, gs)):
+        np.testing.assert_allclose(norms[i, 0].item(), float((p.double() ** 2).sum()), rtol=1e-5)
+        np.testing.assert_allclose(norms[i, 1].item(), float((gr.double() ** 2).sum()), rtol=1e-5, atol=1e-30)
+    trust, lr, wd, eps = 0.02, 0.1, 1e-4, 1e-8
+    want = []
+    for p, gr in zip(ps, gs):
+        pn, gn = p.norm().item(), gr.norm().item()
+        if pn != 0 and gn != 0:
+            rate = min(trust * pn / (gn + pn * wd + eps) / lr, 1.0)
+            want.append((gr + wd * p) * rate)
+        else:
+            want.append(gr.clone())
+    multi.scale(trust, lr, wd, eps, True)
+    for got, ref in zip(gs, want):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=1e-9)

@@ -299,6 +299,53 @@ def test_sgd_and_lars_optimizers_step(mods):
         mods["Model_Util"].get_optimizer(m, B)
 
 
+def test_validate_flow_two_view_eval_step(mods):
+    """validate() of the contrastive driver (Contrastive_Learning.py:751-904, inner step :816-868): model.eval(), two
+    views through the network under no_grad, contrastive_loss on the two embeddings, top-1 / top-5 over logits_ab
+    against the one-hot labels, running means in AverageMeter — every piece from the drop-in modules, against the
+    oracle's eval-mode network on the same weights and buffers."""
+    sys.path.append(SIM)
+    import Utilities
+    B = 16
+    m = _build(mods, "resnet18", 4, 512 * 16, B, (30, 30), 0.25)
+    m.train()
+    warm = [_u8(70 + k, (B, 30, 30, 3)).cuda() for k in range(4)]
+    with torch.no_grad():
+        m(warm)                                      # the running statistics a trained checkpoint would carry
+    m.eval()
+    losses, top1, top5 = Utilities.AverageMeter(), Utilities.AverageMeter(), Utilities.AverageMeter()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    for i in range(2):
+        v1 = [_u8(100 + 10 * i + k, (B, 30, 30, 3)).cuda() for k in range(4)]
+        v2 = [_u8(200 + 10 * i + k, (B, 30, 30, 3)).cuda() for k in range(4)]
+        with torch.no_grad():
+            o1 = m(v1)
+            o2 = m(v2)
+            loss, logits, labels = mods["Objective"].contrastive_loss(hidden1=o1.data, hidden2=o2, temperature=0.05, local_rank=0,
+                                                                      world_size=1, device="cuda")
+        prec1 = mods["Model_Util"].top_k_accuracy(logits, labels, 1)
+        prec5 = mods["Model_Util"].top_k_accuracy(logits, labels, 5)
+        losses.update(Utilities.to_python_float(loss), B)
+        top1.update(Utilities.to_python_float(prec1), B)
+        top5.update(Utilities.to_python_float(prec5), B)
+        # the oracle: eval-mode network (bf16 storage emulation), NT-Xent, top-k
+        x1 = O.pack_views([v.cpu() for v in v1], B, (30, 30))
+        x2 = O.pack_views([v.cpu() for v in v2], B, (30, 30))
+        z1 = O.simclr_forward(sd, x1, "resnet18", training=False, storage="bf16")
+        z2 = O.simclr_forward(sd, x2, "resnet18", training=False, storage="bf16")
+        cos = torch.nn.functional.cosine_similarity(o2.cpu(), z2, dim=1)
+        assert cos.min() > 0.99, cos.min()
+        # the loss / accuracies of the product's own embeddings through the oracle's NT-Xent: tight
+        rl, rlog, rlab = O.nt_xent(o1.cpu(), o2.cpu(), 0.05)
+        np.testing.assert_allclose(loss.item(), rl.item(), rtol=2e-5)
+        assert float(prec1) == float(O.top_k_accuracy(rlog, rlab, 1)) and float(prec5) == float(O.top_k_accuracy(rlog, rlab, 5))
+        assert labels.shape == (B, 2 * B) and logits.shape == (B, B)
+    assert losses.count == 2 * B and 0.0 <= top1.avg <= top5.avg <= 1.0 and np.isfinite(losses.avg)
+    # eval() did not move the BatchNorm buffers
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
+
+
 def test_linear_probe_flow_on_frozen_backbone(mods, tmp_path):
     """the consumer of the checkpoint (Representation_Evaluation.py:406-420,598-712): save_checkpoint ->
     torch.load -> strict load_state_dict -> model.g = Identity -> eval-mode features (running statistics) -> a
@@ -327,19 +374,36 @@ def test_linear_probe_flow_on_frozen_backbone(mods, tmp_path):
     ref = O.backbone_forward(sd, O.pack_views([v.cpu() for v in views], B, (30, 30)), "resnet18", training=False, storage="bf16")
     cos = torch.nn.functional.cosine_similarity(feats.cpu().flatten(1), ref.flatten(1), dim=1)
     assert cos.min() > 0.99
-    probe = mlr.LogisticRegression(512 * 16, 10).cuda()
+    # the probe itself runs on this library too: logits = implicit-GEMM in exact fp32 (1000 classes are padded to the
+    # GEMM's 64-column granularity inside), loss = the softmax-CE kernel (Representation_Evaluation.py:621-666)
+    probe = mlr.LogisticRegression(512 * 16, 1000).cuda()
+    criterion = mlr.HipCrossEntropyLoss()
     opt = torch.optim.SGD(probe.parameters(), lr=0.5)
-    y = torch.arange(B, device="cuda") % 10
+    y = (torch.arange(B, device="cuda") * 37) % 1000
     fx = feats.flatten(1)
     fx = fx / fx.norm(dim=1, keepdim=True)
+    # first step against torch on the same weights
+    w0, b0 = probe.linear.weight.detach().clone(), probe.linear.bias.detach().clone()
+    wt, bt = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    lt = torch.nn.functional.cross_entropy(torch.nn.functional.linear(fx, wt, bt), y)
+    lt.backward()
     l0 = None
-    for _ in range(20):
-        loss = torch.nn.functional.cross_entropy(probe(fx), y)
-        l0 = l0 if l0 is not None else loss.item()
-        opt.zero_grad()
-        loss.backward()
+    for it in range(20):
+        loss = criterion(probe(fx), y.type(torch.long))
+        if it == 0:
+            l0 = loss.item()
+            opt.zero_grad()
+            loss.backward()
+            np.testing.assert_allclose(l0, lt.item(), rtol=1e-5)
+            np.testing.assert_allclose(probe.linear.weight.grad.cpu().numpy(), wt.grad.cpu().numpy(), rtol=1e-3, atol=1e-6)
+            np.testing.assert_allclose(probe.linear.bias.grad.cpu().numpy(), bt.grad.cpu().numpy(), rtol=1e-3, atol=1e-7)
+        else:
+            opt.zero_grad()
+            loss.backward()
         opt.step()
-    assert loss.item() < l0
+    assert loss.item() < l0 and probe(fx).shape == (B, 1000)
+    with pytest.raises(mods["engine"].MaaiError):
+        probe.cpu()(fx.cpu())                     # no CPU fallback here either
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
@@ -546,3 +610,153 @@ def test_eval_mode_inference_fuses_bn_into_every_conv(mods, prec):
     assert "bn_act_fwd" in res["plain"][1]
     # only the four downsample blocks still run a (two-branch) BN pass of their own
     assert res["fused"][1].get("bn_act_fwd", {"launches": 0})["launches"] <= 4
+
+
+# ----------------------------------------------------------------------------
+# the backbone as other parts of the reference use it
+# ----------------------------------------------------------------------------
+class _FrozenBN(torch.nn.Module):
+    """What detr_CLA/models/backbone.py:35-67 passes as ``norm_layer``: buffers only, statistics and affine
+    parameters fixed, eps 1e-5 applied inside forward (written here from that description)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *args)
+
+
+def _varied_stats_sd(arch, cm, head_in, seed):
+    """pattern weights + non-trivial BatchNorm statistics / affine parameters (as a trained checkpoint would hold)"""
+    sd = O.pattern_state_dict(arch, cm, head_in, residual_gamma=0.5)
+    g = torch.Generator().manual_seed(seed)
+    for k in list(sd):
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.2
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 1.5 + 0.5
+        elif ".bn" in k and k.endswith(".bias") or "downsample.1.bias" in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    return sd
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_frozen_bn_backbone_for_dqn_and_detr(mods, prec):
+    """DQN/Q_net.py:17-104 and detr_CLA/models/backbone.py:35-213 reuse ``model.f``: a ResNet-50 built with a
+    frozen-statistics norm layer, fed [B,12,30,30] floats, its layer4 map flattened into MLP heads / transformer
+    tokens, with only layer2-4 trainable.  Features against the oracle's eval-mode backbone (same in train() and
+    eval(), the buffers never move), head outputs, and the gradients that reach the trainable convolutions and the
+    heads against torch autograd through the oracle."""
+    engine = mods["engine"]
+    engine.set_precision(prec)
+    B, cm, head_in = 16, 4, 2048 * 16
+    sd = _varied_stats_sd("resnet50", cm, head_in, 3)
+    f = mods["rn"].resnet50(crop_measures=cm, norm_layer=_FrozenBN)
+    f.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("f.")}, strict=True)
+    f = f.cuda()
+    for name, p in f.named_parameters():                      # BackboneBase.__init__ (backbone.py:72-74)
+        if "layer2" not in name and "layer3" not in name and "layer4" not in name:
+            p.requires_grad_(False)
+    gx, gy = mods["mlp"].MLP(head_in, 1024, 64).cuda(), mods["mlp"].MLP(head_in, 1024, 64).cuda()
+    x = _u8(21, (B, 3 * cm, 30, 30)).float()
+    ref_feat = O.backbone_forward(sd, x, "resnet50", training=False, storage="fp32" if prec == "fp32" else "bf16")
+    buffers = {n: b.clone() for n, b in f.named_buffers()}
+    for mode in ("train", "eval"):
+        getattr(f, mode)()
+        with torch.no_grad():
+            feat = f(x.cuda())
+        assert feat.shape == (B, 2048, 4, 4) and feat.is_contiguous()
+        err = (feat.cpu() - ref_feat).abs().max() / ref_feat.abs().max()
+        assert err < (2e-4 if prec == "fp32" else 3e-2), (mode, float(err))
+    for n, b in f.named_buffers():
+        assert torch.equal(b, buffers[n]), n
+    # DQN.forward: f -> g_x, g_y (Q_net.py:30-41), loss on both heads, backward into heads and layer2-4
+    f.train()
+    feat = f(x.cuda())
+    qx, qy = gx(feat), gy(feat)
+    assert feat.view(B, 2048 * 4 * 4).shape == (B, head_in)   # BackboneBase.forward's view (backbone.py:107)
+    tgt = torch.randn(B, 64, generator=torch.Generator().manual_seed(4)).cuda()
+    loss = ((qx - tgt) ** 2).mean() + ((qy + tgt) ** 2).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    # the same through the oracle with torch autograd
+    work = {k: v.clone() for k, v in sd.items()}
+    leaves = {}
+    for k in ("f.layer4.2.conv3.weight", "f.layer3.0.downsample.0.weight", "f.layer2.1.conv2.weight"):
+        work[k] = leaves[k] = sd[k].clone().requires_grad_(True)
+    rfeat = O.backbone_forward(work, x, "resnet50", training=False, storage="fp32" if prec == "fp32" else "bf16")
+
+    def head(m, v):
+        l0, l2 = m.layers[0], m.layers[2]
+        h = torch.relu(v.reshape(B, -1) @ l0.weight.detach().cpu().t() + l0.bias.detach().cpu())
+        return h @ l2.weight.detach().cpu().t() + l2.bias.detach().cpu()
+    rloss = ((head(gx, rfeat) - tgt.cpu()) ** 2).mean() + ((head(gy, rfeat) + tgt.cpu()) ** 2).mean()
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= (1e-4 if prec == "fp32" else 5e-2) * abs(rloss.item())
+    named = dict(f.named_parameters())
+    assert named["conv1.weight"].grad is None and named["layer1.0.conv1.weight"].grad is None
+    for k, leaf in leaves.items():
+        g = named[k[2:]].grad.cpu()
+        c = torch.nn.functional.cosine_similarity(g.flatten().double(), leaf.grad.flatten().double(), dim=0).item()
+        assert c > (0.9999 if prec == "fp32" else 0.98), (k, c)
+        assert abs(float(g.norm() / leaf.grad.norm()) - 1) < (1e-3 if prec == "fp32" else 6e-2), k
+    assert gx.layers[0].weight.grad is not None and gy.layers[2].bias.grad is not None
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("arch", ["resnet50", "resnet18"])
+def test_blocks_run_on_their_own(mods, arch, prec):
+    """A consumer that walks the backbone's ``layerN`` sub-modules (an intermediate-layer getter; backbone.py:76-82
+    keeps the option): every block is callable by itself — NCHW fp32 in and out, differentiable with respect to an
+    ARBITRARY input (no ReLU assumed upstream) and to its parameters — and ``layer1(x)`` chains them."""
+    engine = mods["engine"]
+    engine.set_precision(prec)
+    storage = "fp32" if prec == "fp32" else "bf16"
+    head_in = (512 if arch == "resnet18" else 2048) * 16
+    sd = O.pattern_state_dict(arch, 1, head_in, residual_gamma=0.5)
+    f = getattr(mods["rn"], arch)(crop_measures=1)
+    f.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("f.")}, strict=True)
+    f = f.cuda().train()
+    plan = O.block_plan(arch)
+    g = torch.Generator().manual_seed(8)
+    cin = f.layer2[0].conv1.in_channels
+    x = torch.randn(4, cin, 16, 16, generator=g)              # signed values: nothing upstream clipped them
+    if prec == "bf16":
+        x = x.bfloat16().float()
+    blocks = [b for b in plan if b["prefix"].startswith("f.layer2.")]
+    xr = x.clone().requires_grad_(True)
+    keys = [k for k in sd if k.startswith("f.layer2.") and k.endswith((".weight", ".bias"))]
+    leaf = {k: sd[k].clone().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(leaf)
+    ref = xr
+    for b in blocks:
+        ref = O.block_forward(work, ref, b, True, storage)
+    xg = x.clone().cuda().requires_grad_(True)
+    out = f.layer2(xg)                                        # nn.Sequential of blocks, each one engine call
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    err = (out.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max()
+    assert err < (2e-4 if prec == "fp32" else 4e-2), float(err)
+    dout = torch.randn(ref.shape, generator=g)
+    ref.backward(dout)
+    out.backward(dout.cuda())
+    torch.cuda.synchronize()
+    named = dict(f.named_parameters())
+
+    def close(a, b, name):
+        c = torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
+        assert c > (0.9999 if prec == "fp32" else 0.985), (name, c)
+        assert abs(float(a.norm() / b.norm()) - 1) < (2e-3 if prec == "fp32" else 6e-2), name
+    close(xg.grad.cpu(), xr.grad, "dx")
+    for k in keys:
+        close(named[k[2:]].grad.cpu(), leaf[k].grad, k)
+    # one block alone, no gradient: same as the oracle's block
+    with torch.no_grad():
+        one = f.layer2[0](x.cuda())
+    r1 = O.block_forward(sd, x, blocks[0], True, storage)
+    assert (one.cpu() - r1).abs().max() <= (2e-4 if prec == "fp32" else 4e-2) * r1.abs().max()
