@@ -1,0 +1,237 @@
+"""Correctness AT the benchmark's sizes (BASELINE configs[1]: ResNet-50, 3x224x224, 256 images per GPU) — the tile
+shapes, halo patches on 224^2 / 112^2 planes, patch-staged weight gradients and > 2^31-element tensors that the small
+parity cases never reach.  The oracle cannot evaluate these tensors whole in seconds, so each kernel is checked
+  (a) on sampled output windows against the fp64 oracle evaluated on the matching input crop (32 images), and
+  (b) through size-independent properties at the full 256 images: a convolution / BatchNorm pass / weight gradient over
+      the whole batch equals the same kernel run on 32-image slices (bit for bit where the arithmetic is per image,
+      to fp32 rounding where sums are taken in a different order).
+Reference semantics: resnet.py:20-28,101-135 (conv / bn / relu of a Bottleneck)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from maai_hip import kernels
+    return kernels
+
+
+def _rand_bf16(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, device="cuda", generator=g) * scale).bfloat16()
+
+
+def _window_ref(x, w, n, oy, ox, size, k, stride, pad):
+    """fp64 convolution of image n restricted to output rows/cols [oy, oy+size) x [ox, ox+size): crop the input
+    (zero padding where the crop leaves the image) and convolve without padding."""
+    H, W = x.shape[1], x.shape[2]
+    iy0, ix0 = oy * stride - pad, ox * stride - pad
+    span = (size - 1) * stride + k
+    crop = torch.zeros((1, x.shape[3], span, span), dtype=torch.float64)
+    ys = slice(max(iy0, 0), min(iy0 + span, H))
+    xs = slice(max(ix0, 0), min(ix0 + span, W))
+    crop[0, :, ys.start - iy0:ys.stop - iy0, xs.start - ix0:xs.stop - ix0] = x[n, ys, xs, :].double().cpu().permute(2, 0, 1)
+    return F.conv2d(crop, w.double().cpu().permute(0, 3, 1, 2), None, stride)[0].permute(1, 2, 0)   # [size, size, Cout]
+
+
+FWD_LAYERS = [
+    # name, H, Cin, Cout, k, stride
+    ("layer1 conv2 3x3 C64 @224 (halo)", 224, 64, 64, 3, 1),
+    ("layer1 conv1 1x1 256->64 @224", 224, 256, 64, 1, 1),
+    ("layer1 conv3 1x1 64->256 @224", 224, 64, 256, 1, 1),
+    ("layer2.0 conv2 3x3 C128 stride 2 @224", 224, 128, 128, 3, 2),
+    ("layer2 conv2 3x3 C128 @112 (halo)", 112, 128, 128, 3, 1),
+    ("layer2.0 downsample 1x1 256->512 stride 2 @224", 224, 256, 512, 1, 2),
+    ("layer3 conv2 3x3 C256 @56 (256-row tile)", 56, 256, 256, 3, 1),
+    ("stem 7x1 over the kw-unrolled operand @224", 224, 32, 64, 7, 1),
+]
+
+
+@pytest.mark.parametrize("layer", FWD_LAYERS, ids=lambda l: l[0])
+def test_forward_conv_windows_and_statistics_at_224(K, layer):
+    name, H, cin, cout, k, stride = layer
+    N = 32
+    pad = k // 2
+    x = _rand_bf16((N, H, H, cin), 1)
+    if k == 7:   # the stem's operand: 7x1 taps over 32 (= 8 kw x 4) channels
+        w = _rand_bf16((cout, 7, 1, cin), 2, 1.0 / (7 * cin) ** 0.5)
+        y, part = K.conv2d(x, w, 1, 3, 0, stats=True)
+    else:
+        w = _rand_bf16((cout, k, k, cin), 2, 1.0 / (k * k * cin) ** 0.5)
+        y, part = K.conv2d(x, w, stride, pad, pad, stats=True)
+    torch.cuda.synchronize()
+    OH = y.shape[1]
+    rng = np.random.default_rng(7)
+    windows = [(0, 0, 0), (N - 1, OH - 8, OH - 8), (5, 0, OH - 8), (17, OH - 8, 0)] + \
+              [(int(rng.integers(N)), int(rng.integers(OH - 8)), int(rng.integers(OH - 8))) for _ in range(6)]
+    for (n, oy, ox) in windows:
+        if k == 7:
+            crop = torch.zeros((1, cin, 8 + 6, 8), dtype=torch.float64)
+            ys = slice(max(oy - 3, 0), min(oy + 11, H))
+            crop[0, :, ys.start - (oy - 3):ys.stop - (oy - 3), :] = x[n, ys, ox:ox + 8, :].double().cpu().permute(2, 0, 1)
+            ref = F.conv2d(crop, w.double().cpu().permute(0, 3, 1, 2))[0].permute(1, 2, 0)
+        else:
+            ref = _window_ref(x, w, n, oy, ox, 8, k, stride, pad)
+        got = y[n, oy:oy + 8, ox:ox + 8, :].double().cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1.0 / 128, atol=2e-2, err_msg="%s window %s" % (name, (n, oy, ox)))
+    # BatchNorm statistics of the whole tensor: the epilogue's fp32 partial sums against the stored output itself
+    sums = K.reduce_partials(part).cpu()
+    yf = y.float()
+    s1 = yf.sum(dim=(0, 1, 2), dtype=torch.float64).cpu()
+    s2 = (yf.double() ** 2).sum(dim=(0, 1, 2)).cpu()
+    m = N * OH * OH
+    np.testing.assert_allclose(sums[:cout].numpy(), s1.numpy(), rtol=1e-3, atol=1e-2 * m ** 0.5)   # (y is rounded to bf16: ~2^-9 |y| per element, random walk over m)
+    np.testing.assert_allclose(sums[cout:].numpy(), s2.numpy(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("layer", [("3x3 C64 @224", 224, 64, 64, 3, 1), ("1x1 64->256 @224 (3.3e9 output elements)", 224, 64, 256, 1, 1),
+                                   ("1x1 256->64 @224 (3.3e9 input elements)", 224, 256, 64, 1, 1), ("3x3 C128 @112", 112, 128, 128, 3, 1)],
+                         ids=lambda l: l[0])
+def test_batch_split_invariance_at_256_images(K, layer):
+    """conv(x) over 256 images == conv over 32-image slices, bit for bit (each output pixel depends on its own image
+    only), and so are the BatchNorm partial sums (same tiles, summed in fp64)."""
+    name, H, cin, cout, k, stride = layer
+    N, S = 256, 32
+    pad = k // 2
+    x = _rand_bf16((N, H, H, cin), 11)
+    w = _rand_bf16((cout, k, k, cin), 12, 1.0 / (k * k * cin) ** 0.5)
+    y, part = K.conv2d(x, w, stride, pad, pad, stats=True)
+    total = K.reduce_partials(part)
+    acc = torch.zeros_like(total)
+    for i in range(0, N, S):
+        ys, ps = K.conv2d(x[i:i + S].contiguous(), w, stride, pad, pad, stats=True)
+        assert torch.equal(ys, y[i:i + S]), "%s: images %d..%d differ from the whole-batch launch" % (name, i, i + S)
+        acc += K.reduce_partials(ps)
+        del ys, ps
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(acc.cpu().numpy(), total.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    assert float(y[-1].float().abs().max()) > 0.1   # the tail of the tensor was written
+
+
+def test_lazy_and_join_convolutions_at_256_images(K):
+    """The normalise-on-load launches at the benchmark's layer-1 shapes (the ones the engine's policy uses), 256 images:
+    bit-identical to the BatchNorm pass + plain launch, including the joined activation and its mask bits handed back
+    by the residual join (3.3e9 elements each)."""
+    N, H = 256, 224
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y1 = _rand_bf16((N, H, H, 64), 21)
+    s64, t64 = torch.rand(64, device="cuda", generator=g) + 0.5, torch.randn(64, device="cuda", generator=g) * 0.3
+    act = K.bn_act_fwd(y1, s64, t64, None, True)
+    for (cout, k) in ((64, 3), (256, 1)):
+        w = _rand_bf16((cout, k, k, 64), 22 + k, 1.0 / (k * k * 64) ** 0.5)
+        ref, rp = K.conv2d(act, w, 1, k // 2, k // 2, stats=True)
+        got, gp = K.conv2d(K.Lazy(y1, s64, t64, True), w, 1, k // 2, k // 2, stats=True)
+        assert torch.equal(got, ref) and torch.equal(gp, rp), (cout, k)
+        del ref, got, rp, gp
+    del act, y1
+    y3 = _rand_bf16((N, H, H, 256), 31)
+    res = _rand_bf16((N, H, H, 256), 32).clamp_min(0)
+    s, t = torch.rand(256, device="cuda", generator=g) + 0.5, torch.randn(256, device="cuda", generator=g) * 0.3
+    w = _rand_bf16((64, 1, 1, 256), 33, 1.0 / 16)
+    joined, bits = K.bn_act_fwd(y3, s, t, res, True, want_bits=True)
+    ref, rp = K.conv2d(joined, w, stats=True)
+    got, gp, j2, b2 = K.conv2d(K.Lazy(y3, s, t, True, res), w, stats=True, join_out=True, join_bits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and torch.equal(gp, rp)
+    assert torch.equal(j2, joined) and torch.equal(b2, bits)
+
+
+def test_batchnorm_pass_at_256_images(K):
+    """The streaming BatchNorm + residual + ReLU pass (non-temporal accesses, 32768-block grid) on a 3.3e9-element
+    tensor: every 32-image slice equals the pass run on that slice alone; mask bits agree with the output."""
+    N, H, C, S = 256, 224, 256, 32
+    y = _rand_bf16((N, H, H, C), 41)
+    res = _rand_bf16((N, H, H, C), 42)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    s, t = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.3
+    out, bits = K.bn_act_fwd(y, s, t, res, True, want_bits=True)
+    for i in (0, 96, N - S):
+        o, b = K.bn_act_fwd(y[i:i + S].contiguous(), s, t, res[i:i + S].contiguous(), True, want_bits=True)
+        assert torch.equal(o, out[i:i + S])
+        per = b.numel() // S                     # mask bytes per image
+        assert torch.equal(b, bits[i * per:(i + S) * per])
+    # against fp32 torch on one slice
+    i = 128
+    ref = torch.relu(y[i:i + 4].float() * s + t + res[i:i + 4].float()).bfloat16()
+    assert torch.equal(out[i:i + 4], ref)
+    # backward apply on the same size: dy = k1*dz - k2 - k3*y, slice-wise identical
+    k1, k2, k3 = s, t * 0.01, s * 0.001
+    dy, _ = K.bn_act_bwd_apply(res, None, y, k1, k2, k3, False, True, False)
+    i = 64
+    d2, _ = K.bn_act_bwd_apply(res[i:i + S].contiguous(), None, y[i:i + S].contiguous(), k1, k2, k3, False, True, False)
+    assert torch.equal(d2, dy[i:i + S])
+
+
+@pytest.mark.parametrize("layer", [("patch-staged 3x3 C64 @224", 224, 64, 64, 3), ("ring 1x1 64->256 @224", 224, 64, 256, 1),
+                                   ("ring 1x1 256->64 @224", 224, 256, 64, 1), ("patch-staged 3x3 C128 @112", 112, 128, 128, 3)],
+                         ids=lambda l: l[0])
+def test_weight_gradient_at_timed_size(K, layer):
+    """dW over 256 images: equals the sum of dW over 32-image slices (fp32 summation order aside), and on 4 images the
+    fp64 oracle (torch autograd of conv2d)."""
+    name, H, cin, cout, k = layer
+    N, S = 256, 32
+    pad = k // 2
+    x = _rand_bf16((N, H, H, cin), 51)
+    dy = _rand_bf16((N, H, H, cout), 52, 0.05)
+    K.AUTOTUNE[0] = False
+    try:
+        dw = K.conv2d_wgrad(x, dy, k, k, 1, pad, pad)
+        acc = torch.zeros_like(dw, dtype=torch.float64)
+        for i in range(0, N, S):
+            acc += K.conv2d_wgrad(x[i:i + S].contiguous(), dy[i:i + S].contiguous(), k, k, 1, pad, pad).double()
+        torch.cuda.synchronize()
+        scale = float(acc.abs().max())
+        assert float((dw.double() - acc).abs().max()) <= 1e-3 * scale, name   # (fp32 atomics: the two runs sum in different orders)
+        # 4 images against fp64 autograd
+        xs, ds = x[:4].contiguous(), dy[:4].contiguous()
+        got = K.conv2d_wgrad(xs, ds, k, k, 1, pad, pad).cpu().double()
+    finally:
+        K.AUTOTUNE[0] = True
+    wz = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xs.double().cpu().permute(0, 3, 1, 2), wz, None, 1, pad).backward(ds.double().cpu().permute(0, 3, 1, 2))
+    ref = wz.grad.permute(0, 2, 3, 1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+
+
+def test_resnet50_at_224_first_stage_teacher_forced():
+    """The drop-in model on 224x224 images (4 of them: what the oracle does in seconds): the stem and every block of
+    layer1 — the 224^2 planes where the halo / patch kernels and the lazy policy are active — against the oracle's
+    block evaluated on the HIP path's own block input, forward, in the benchmarked bf16 mode."""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    SIM = os.path.join(ROOT, "multimodal-active-ai_amd", "SimCLR")
+    for d in (SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP")):
+        if d not in sys.path:
+            sys.path.append(d)
+    import resnet as rn
+    from maai_hip import engine
+    from oracle import simclr_oracle as O
+    torch.set_num_threads(16)
+    engine.set_precision("bf16")
+    sd = O.pattern_state_dict("resnet50", 1, 2048 * 16, residual_gamma=0.5)
+    f = rn.resnet50(crop_measures=1)
+    f.load_state_dict({k[2:]: v for k, v in sd.items() if k.startswith("f.")}, strict=True)
+    f = f.cuda().train()
+    g = torch.Generator().manual_seed(13)
+    x = torch.randint(0, 256, (4, 3, 224, 224), generator=g).float()
+    engine.set_lazy(True, True, "auto")
+    with torch.no_grad():
+        _, tape = engine.backbone_fwd(f, x.cuda(), engine.compute_dtype(), keep=True)
+    stem = engine.unit_output(tape[0][1]).float().cpu().permute(0, 3, 1, 2)
+    ref = O.stem_forward(sd, x, True, "bf16")
+    assert (stem - ref).abs().max() <= 2.0 ** -6 * ref.abs().max()
+    plan = [b for b in O.block_plan("resnet50") if b["prefix"].startswith("f.layer1.")]
+    for entry, blk in zip(tape[1:4], plan):
+        _, r1, r2, r3, rd = entry
+        x_in = engine.materialise(r1.x).float().cpu().permute(0, 3, 1, 2).contiguous()
+        want = O.block_forward(sd, x_in, blk, True, "bf16")
+        got = r3.out.float().cpu().permute(0, 3, 1, 2)
+        err = (got - want).abs().max() / want.abs().max()
+        assert err <= 2.0 ** -6, (blk["prefix"], float(err))
