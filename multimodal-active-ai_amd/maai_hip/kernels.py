@@ -321,6 +321,32 @@ def conv2d_bwd_apply(x, w, dz, k1, k2, k3, stride=1, pad_h=0, pad_w=0):
 _WGRAD_TUNE = {}
 WGRAD_CANDIDATES = (768, 1536, 3072)
 AUTOTUNE = [os.environ.get("MAAI_AUTOTUNE", "1") != "0"]
+# MAAI_WGRAD_TUNE_FILE: the measured split-K budgets are read from / appended to this JSON file, so that a profiled
+# run (rocprofv3) of a workload tuned before contains no tuning launches
+_TUNE_FILE = os.environ.get("MAAI_WGRAD_TUNE_FILE", "")
+
+
+def _tune_load():
+    if _TUNE_FILE and os.path.exists(_TUNE_FILE):
+        import json
+        try:
+            with open(_TUNE_FILE) as fh:
+                for k, v in json.load(fh).items():
+                    _WGRAD_TUNE[tuple(int(t) for t in k.split(","))] = int(v)
+        except (ValueError, OSError):
+            pass
+
+
+def _tune_save():
+    if _TUNE_FILE:
+        import json
+        tmp = "%s.%d.tmp" % (_TUNE_FILE, os.getpid())
+        with open(tmp, "w") as fh:
+            json.dump({",".join(str(t) for t in k): v for k, v in _WGRAD_TUNE.items()}, fh)
+        os.replace(tmp, _TUNE_FILE)
+
+
+_tune_load()
 
 
 def _wgrad_target(d, x, dy, dtype_code):
@@ -346,6 +372,7 @@ def _wgrad_target(d, x, dy, dtype_code):
         if best_ms is None or m < best_ms:
             best, best_ms = cand, m
     _WGRAD_TUNE[key] = best
+    _tune_save()
     return best
 
 
