@@ -1,6 +1,9 @@
 // The implicit-GEMM convolution kernel template and its launcher, shared by conv_fwd.hip (plain / epilogue-fused
 // launches) and conv_xf.hip (launches whose A operand is normalised on the way in).  See conv_fwd.hip for the design.
 #pragma once
+#ifndef MAAI_EXP
+#define MAAI_EXP 0   // experiment bits for A/B builds (scripts/build_variant.sh); 0 = the shipped kernel
+#endif
 #include "common.h"
 #include "maai_internal.h"
 #include <stdlib.h>
@@ -475,10 +478,16 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
     for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const frag_t*>(sa + i * (HALO ? 24 * 64 : 16 * 64));
 #pragma unroll
     for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
+#if MAAI_EXP & 1
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+#if MAAI_EXP & 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if constexpr (XF != 0) {
       if (kt + 1 < KT) {
         // behind this step's MFMAs: retire stage kt+1 (stages kt+2 .. may stay in flight) and transform it

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must come first: libmaai_hip.so has to bind to the 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmaai_hip.so")
+LIB_PATH = os.environ.get("MAAI_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libmaai_hip.so")   # (MAAI_LIB_PATH: A/B builds of the kernels)
 
 BF16, F32 = 0, 1
 

@@ -824,23 +824,25 @@ def _joins_on_load(blk, dtype):
             and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0 and not _fusable(c1, "fwd"))
 
 
-def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False):
+def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None):
     """One residual block (resnet.py:59-77 / :113-135).  ``xin``: a tensor or a ``kernels.Lazy`` activation (the stem's,
     or the previous block's residual join).  ``lazy_out``: return the block output as a Lazy join for the next
     block's conv1 to form.  Returns (out, (r1, r2, r3, rd), xin tensor or single-tensor Lazy as materialised here,
     1-bit mask of xin or None)."""
     g1, g2, g3, gd = given if given is not None else (None, None, None, None)
     side = {}
+    if pol_keep is None:
+        pol_keep = keep   # does a weight gradient read this forward's activations? (not when the block is recomputed)
     needs_identity = blk.downsample is None
     if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or (xin.b is not None and not _joins_on_load(blk, dtype))):
         xin = materialise(xin)   # the identity shortcut reads it / conv1 cannot join it
     nxt = blk.conv2
-    o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=_lazy_pays([nxt], keep), side=side)
+    o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=_lazy_pays([nxt], pol_keep), side=side)
     xin_bits = side.get("bits")
     if isinstance(xin, K.Lazy) and xin.b is not None:
         xin = side["joined"]     # conv1 formed the join and handed it back
     if _is_bottleneck(blk):
-        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=_lazy_pays([blk.conv3], keep))
+        o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=_lazy_pays([blk.conv3], pol_keep))
         last_conv, last_bn = blk.conv3, blk.bn3
     else:  # BasicBlock
         r2 = None
@@ -870,17 +872,18 @@ def backbone_fwd(resnet, x, dtype, keep):
     blocks = list(_blocks(resnet))
     # the stem's activation is formed on load by layer1's first convolutions when that block has a projection
     # shortcut (an identity shortcut would read the tensor itself)
+    ckpt = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
     stem_lazy = (bool(blocks) and blocks[0].downsample is not None and not _fusable(blocks[0].conv1, "fwd")
                  and not _fusable(blocks[0].downsample[0], "fwd") and _lazy_pays([blocks[0].conv1, blocks[0].downsample[0]], keep))
     K.FLOPS_SCALE[0] = (49.0 * cin) / (wq.shape[1] * wq.shape[2] * wq.shape[3])  # executed K includes zero padding
     out, r = unit_fwd(xs, resnet.conv1, resnet.bn1, True, None, dtype, keep, wq=wq, form=form, lazy_out=stem_lazy)
     K.FLOPS_SCALE[0] = 1.0
     tape.append(("stem", r))
-    ckpt = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
     prev3 = None   # record of the previous block's last unit while its output is still a Lazy join
     for i, blk in enumerate(blocks):
         lazy_out = i + 1 < len(blocks) and _joins_on_load(blocks[i + 1], dtype) and _FUSE["max_cin"] == 0
-        out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out)
+        # (block recompute: this forward's activations are dropped and rebuilt, so it runs with the no-backward policy)
+        out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out, pol_keep=keep and not ckpt)
         if prev3 is not None:
             prev3.out, prev3.bits = xin, xin_bits   # the join this block's conv1 formed IS the previous block's output
         prev3 = recs[2] if (lazy_out and keep) else None
@@ -969,7 +972,9 @@ def backbone_bwd(tape, dout, grads, dtype):
             # rebuild this block's records from its input and the saved statistics, differentiate, drop them; the
             # block below is not materialised yet, so its BN-backward sums cannot ride this block's last epilogue
             _, blk, xin, lights, _ = entry
-            _, recs, _, _ = _block_fwd(blk, xin, dtype, True, given=lights)
+            # (lazy_out: the rebuilt block's OUTPUT is not needed again — the gradient arriving here is already masked and
+            #  the block above was differentiated from its own stored input — so its last BatchNorm pass is not re-run)
+            _, recs, _, _ = _block_fwd(blk, xin, dtype, True, given=lights, lazy_out=True)
             dout, sums = block_bwd(("block",) + recs, dout, grads, dtype, prev=None, presums=sums)
             tape[i] = None
             del recs
