@@ -66,11 +66,16 @@ def _cached(param, tag, dtype, build):
     key = (id(param), tag, dtype)
     ver = (param._version, _WEIGHT_EPOCH[0], param.data_ptr())
     hit = _CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    # (the entry must belong to THIS parameter object: a destroyed model's id and allocator address can both be
+    #  recycled by the next one, with _version 0 again)
+    if hit is not None and hit[0] == ver and hit[2]() is param:
         return hit[1]
     with torch.no_grad():
         t = build(param.detach())
-    _CACHE[key] = (ver, t)
+    if len(_CACHE) > 64:
+        for k in [k for k, h in _CACHE.items() if h[2]() is None]:
+            del _CACHE[k]
+    _CACHE[key] = (ver, t, weakref.ref(param))
     return t
 
 
