@@ -79,6 +79,11 @@ def wgrad_case(name, hw, cin, cout, k, stride=1):
 
 if __name__ == "__main__":
     print("B = %d" % B)
+    if len(sys.argv) > 2 and sys.argv[2] == "wgrad":
+        wgrad_case("l2.0 conv2 128->128 k3 s2 @224", 224, 128, 128, 3, 2)
+        wgrad_case("l1.0 conv1 64->64 k1 @224 (stem)", 224, 64, 64, 1)
+        wgrad_case("l1.0 downsample 64->256 k1 @224 (stem)", 224, 64, 256, 1)
+        sys.exit(0)
     fwd_case("stem->l1 64->64 k1 @224", 224, 64, 64, 1)
     fwd_case("l1 conv2 64->64 k3 @224", 224, 64, 64, 3)
     fwd_case("l1 conv3 64->256 k1 @224", 224, 64, 256, 1)
@@ -93,6 +98,8 @@ if __name__ == "__main__":
     join_case("l2 conv1 512->128 @112", 112, 512, 128)
     join_case("l3 conv1 1024->256 @56", 56, 1024, 256)
     join_case("l4 conv1 2048->512 @28", 28, 2048, 512)
+    wgrad_case("l2.0 conv2 128->128 k3 s2 @224", 224, 128, 128, 3, 2)
+    wgrad_case("l1.0 conv1 64->64 k1 @224 (stem)", 224, 64, 64, 1)
     wgrad_case("l1 conv2 64->64 k3 @224", 224, 64, 64, 3)
     wgrad_case("l1 conv3 64->256 k1 @224", 224, 64, 256, 1)
     wgrad_case("l2 conv2 128->128 k3 @112", 112, 128, 128, 3)
