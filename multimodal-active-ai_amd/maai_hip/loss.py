@@ -31,7 +31,12 @@ def prefetch_embedding(h):
     """Start the all-gather of normalize(h) on the side stream (maai_hip.dist.prefetch_embedding); a later
     contrastive_loss(h.data, ...) / contrastive_loss(..., h) with hidden_norm=True picks it up."""
     if D.is_distributed() and h.is_cuda and h.dim() == 2:
-        D.prefetch_embedding(h, lambda t: K.ntxent_normalize(t, True))
+        try:
+            D.prefetch_embedding(h, lambda t: K.ntxent_normalize(t, True))
+        except RuntimeError as e:   # the loss then gathers on the compute stream, as it does without a prefetch
+            D.STATS["prefetch_failed"] = D.STATS.get("prefetch_failed", 0) + 1
+            import warnings
+            warnings.warn("embedding prefetch failed (%s); falling back to the gather inside contrastive_loss" % e)
 
 
 class _NTXentFn(torch.autograd.Function):

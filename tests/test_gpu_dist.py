@@ -24,15 +24,16 @@ def _paths():
             sys.path.insert(0, d)
 
 
-def _model(world, B):
+def _model(world, B, arch="resnet18"):
     _paths()
     import resnet as rn
     import multilayerPerceptron as mlp
     import SimCLR
     from oracle import simclr_oracle as O
     norm = torch.nn.SyncBatchNorm if world > 1 else torch.nn.BatchNorm2d
-    m = SimCLR.SimCLR_Module(rn.resnet18(crop_measures=1, norm_layer=norm), mlp.MLP(512 * 16, 1024, 128), B, (32, 32), "cuda")
-    m.load_state_dict(O.pattern_state_dict("resnet18", 1, 512 * 16, residual_gamma=0.25), strict=True)
+    head_in = 512 * O.expansion(arch) * 16
+    m = SimCLR.SimCLR_Module(getattr(rn, arch)(crop_measures=1, norm_layer=norm), mlp.MLP(head_in, 1024, 128), B, (32, 32), "cuda")
+    m.load_state_dict(O.pattern_state_dict(arch, 1, head_in, residual_gamma=0.25), strict=True)
     return m.cuda().train()
 
 
@@ -41,7 +42,7 @@ def _inputs(B):
     return (torch.randint(0, 256, (B, 3, 32, 32), generator=g).float(), torch.randint(0, 256, (B, 3, 32, 32), generator=g).float())
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", arch="resnet18"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,7 +60,9 @@ def _worker(rank, world, port, q, backend="gloo"):
     B = 16
     b = B // world
     x1, x2 = _inputs(B)
-    m = _model(world, b)
+    m = _model(world, b, arch)
+    if arch == "resnet50":
+        engine.set_lazy(True, True, "all")     # every lazy / join launch under SyncBatchNorm, not only the policy's
     sl = slice(rank * b, (rank + 1) * b)
     # step A: no gradient exchange -> the local gradient of this rank
     with torch.no_grad():
@@ -68,7 +71,8 @@ def _worker(rank, world, port, q, backend="gloo"):
     loss, logits, labels = Objective.contrastive_loss(h1.data, h2, temperature=0.5, local_rank=rank, world_size=world, device="cuda")
     loss.backward()
     torch.cuda.synchronize()
-    g_local = {n: p.grad.clone() for n, p in m.named_parameters() if n in ("f.conv1.weight", "g.layers.2.bias", "f.layer3.0.bn2.weight")}
+    g_local = {n: p.grad.clone() for n, p in m.named_parameters()
+               if n in ("f.conv1.weight", "g.layers.2.bias", "f.layer3.0.bn2.weight", "f.layer2.0.downsample.1.weight")}
     rm = m.f.bn1.running_mean.cpu().numpy()
     hits_a = D.STATS["prefetch_hits"]
     # step B, same weights and inputs: gradient buckets go out from inside the backward pass (engine hook)
@@ -89,26 +93,30 @@ def _worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-def test_two_ranks_rccl():
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_two_ranks_rccl(arch):
     """The same protocol with one MI355X per rank over RCCL (backend 'nccl')."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device")
     if torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
-    _run_two_ranks("nccl", 29743)
+    _run_two_ranks("nccl", 29743, arch)
 
 
-def test_two_ranks_match_single_process():
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_two_ranks_match_single_process(arch):
+    """resnet50: Bottleneck blocks — the projection-shortcut pair's statistics in one exchange, forward and backward,
+    and every normalise-on-load / join launch fed by all-reduced statistics."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a HIP device")
-    _run_two_ranks("gloo", 29741)
+    _run_two_ranks("gloo", 29741 if arch == "resnet18" else 29745, arch)
 
 
-def _run_two_ranks(backend, port):
+def _run_two_ranks(backend, port, arch="resnet18"):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, backend, arch)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
@@ -119,7 +127,7 @@ def _run_two_ranks(backend, port):
     engine.set_precision("fp32")
     B = 16
     x1, x2 = _inputs(B)
-    m = _model(1, B)
+    m = _model(1, B, arch)
     with torch.no_grad():
         h1 = m.forward_tensor(x1.cuda())
         h2 = m.forward_tensor(x2.cuda())
