@@ -152,6 +152,27 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
   return launch_conv_p<bf16_t, 256, BN, 3, 0, false, true>(a, st);
 }
 
+// The streaming kernel (conv_pws.hip) takes the channel-EXPANDING pointwise stride-1 bf16 layers with 64 / 128 / 256
+// input channels (conv3 of the bottlenecks of layers 1-3, the stride-1 projection shortcut).  Measured against the ring
+// kernel (scripts/pws_ab.py, B = 256, per launch): 64->256@224 1.72 -> 1.63 ms (normalise-on-load 1.99 -> 1.65),
+// 128->512@112 1.20 -> 0.96 (1.40 -> 0.97), 256->1024@56 0.79 -> 0.64 (0.94 -> 0.66), 256->512@56 0.39 -> 0.37 (0.48 ->
+// 0.39); equal-channel and channel-reducing layers stay on the ring kernel (-2 ... -11 %).  Its statistics slab has one
+// row per 128 pixels, so the row count and the launch decide with this same function (a ReLU mask, which the row count
+// cannot see, keeps the ring kernel on 128-row tiles).  MAAI_CONV_PWS = 0 (off) | 1 (shape rule, default) | 2 (every
+// shape the kernel is built for), read per call.
+static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype) {
+  const char* e = getenv("MAAI_CONV_PWS");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  // a forced ring-kernel tile (the parity tests sweep those knobs) means the ring kernel
+  if (mode == 1 && (getenv("MAAI_CONV_BM") || getenv("MAAI_CONV_BN") || getenv("MAAI_CONV_NSTAGE"))) return false;
+  const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+  if (!(dtype == MAAI_BF16 && pw1 && (d->Cin == 64 || d->Cin == 128 || d->Cin == 256) && d->Cout % 64 == 0)) return false;
+  if (d->accumulate || d->out_stride != 1 || d->OH != d->OHg || d->OW != d->OWg) return false;
+  if (epi && (epi->mode != MAAI_EPI_STORE || epi->a2)) return false;
+  return mode == 2 || d->Cout >= 2 * d->Cin;
+}
+
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                  const void* relu_mask, int dtype, void* stream) {
   return maai_conv2d_igemm_fused(d, x, w, y, stats_partial, relu_mask, nullptr, dtype, stream);
@@ -233,13 +254,19 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     plan.bm = 128;
     plan.nMB = (a.M + 127) / 128;
   }
-  const int bm = plan.bm;
   a.nMB = (int)plan.nMB;
   a.tilesX = plan.tilesX;
   a.tilesY = plan.tilesY;
   ConvSel sel;
-  sel.dtype = dtype; sel.bm = bm; sel.halo = plan.halo; sel.nstage = 3;
+  sel.dtype = dtype; sel.bm = plan.bm; sel.halo = plan.halo; sel.nstage = 3;
   sel.pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+  if (pws_selected(d, epi, dtype)) {
+    a.nMB = (int)((a.M + 127) / 128);
+    if (!relu_mask) return maai_conv_pws_launch(a, st);
+    plan.bm = 128;   // the slab rows promised for this shape
+    sel.bm = 128;
+  }
+  const int bm = plan.bm;
   if (plan.halo) {
     const bool h128 = d->Cout % 128 == 0;
     a.nNB = d->Cout / (h128 ? 128 : 64);
@@ -294,10 +321,10 @@ extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const
     return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   const ConvPlan p = conv_plan(d, dtype);
   if (epi && epi->xs && p.bm == 64) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  if (pws_selected(d, epi, dtype)) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   return p.nMB;
 }
 
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {
-  if (!d) return 0;
-  return conv_plan(d, dtype).nMB;
+  return maai_conv2d_stats_rows_fused(d, nullptr, dtype);
 }

@@ -1,0 +1,302 @@
+// Streaming kernel for the pointwise stride-1 layers with few input channels (Cin <= 256, bf16): the HBM-bound 1x1
+// convolutions of the first bottleneck stages (resnet.py:101-109 conv1 / conv3, the projection shortcuts) and the data
+// gradients with the same shape.
+//
+// The ring kernel of conv_igemm.h keeps at most NSTAGE-1 K-steps of the A operand in flight per workgroup — 16 KB
+// against an HBM latency that wants ~40 KB per CU — and re-stages A once per column tile.  Here the A operand never
+// touches LDS: each wave loads the whole K extent of ITS 32 pixel rows straight into registers in MFMA layout (every
+// byte of the tile in flight at once, read from HBM exactly once per launch), and the workgroup then walks ALL column
+// tiles of the output, streaming only the weights (L2-resident) through a small LDS-DMA ring.  The wave grid is 4x1, so
+// a wave owns full output rows: its C tile goes through a PRIVATE LDS area to 16-byte row stores with no workgroup
+// barrier, and the weight prefetch for the next column tile keeps running under the epilogue.
+// Normalise-on-load (XF 1; XF 2 = the two-tensor residual join with its side outputs) is applied to the registers once
+// per element (the ring kernel repeats it per column tile).
+// Same MFMA sequence per output element as conv_igemm_kernel (K ascending, 32 per instruction): identical bits.
+#include "conv_igemm.h"
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// KC = Cin; BN = column tile; DIST = weight stages in flight ahead of the one being multiplied (a stage = 32 input
+// channels x BN output channels).  The ring has DIST + 2 slots: the slot refilled after the barrier of step s is the
+// one read in step s-2, whose MFMAs every wave has ISSUED (hence whose LDS reads have returned) before it reached the
+// barrier of step s-1 — safe wherever the compiler schedules the MFMAs of step s-1 around the barrier of step s (the
+// K loop is fully unrolled here and hipcc does sink them below it, with their fragment reads still outstanding).
+// EMODE 0: plain store (+ statistics slab); 5: accumulate and/or ReLU mask; 6: 5 + BN-backward sums (DGRAD_REDUCE).
+template <int KC, int BN, int DIST, int XF, int EMODE>
+__global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
+  typedef bf16_t T;
+  constexpr int TM = 2, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
+  constexpr int LDC = BN + 8;              // private C tile row pitch (elements)
+  constexpr int CW = 16 * LDC * 2;         // bytes of one wave's 16-row C area
+  constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
+  constexpr int RPI = 64 / CPR;            // rows one wave-wide 16-byte access covers
+  constexpr int NIT = 16 / RPI;            // such accesses per 16-row group
+  constexpr int NST = TM * NIT;            // global stores per wave per column tile
+  constexpr int NSLOT = DIST + 2;
+  constexpr int RING = NSLOT * STAGE;
+  typedef Mma<T>::frag frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + RING + 4 * CW);       // [4 waves x 4 lane groups][2][BN]
+  float* xcoef = reinterpret_cast<float*>(smem + RING);                                                  // XF: xs | xt, KC floats each — in the C area, which nothing else uses before the first epilogue
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  const int mb = xcd_remap(blockIdx.x, a.nMB);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+  T* __restrict__ y = reinterpret_cast<T*>(a.y);
+  const int nCT = a.Cout / BN;
+  const int S = nCT * KT;                  // weight stages of this workgroup
+  const bool full = (long long)(mb + 1) * 128 <= a.M;
+
+  if constexpr (XF != 0) {
+    const int nco = (XF == 2 && a.xs2) ? 4 * KC : 2 * KC;
+    for (int i = tid; i < nco; i += 256) {
+      const int which = i / KC, c = i - which * KC;
+      xcoef[i] = which == 0 ? a.xs[c] : (which == 1 ? a.xt[c] : (which == 2 ? a.xs2[c] : a.xt2[c]));
+    }
+  }
+
+  // ---- the A operand: rows mb*128 + wid*32 + i*16 + (lane & 15), channels kt*32 + (lane >> 4)*8 .. +8 ----
+  const long long arow0 = (long long)mb * 128 + widu * 32;
+  uint4 areg[TM][KT];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = arow0 + i * 16 + (lane & 15);
+    const T* src = x + (m < a.M ? m : a.M - 1) * KC + (lane >> 4) * 8;   // unconditional loads; rows past the end are zeroed below
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) areg[i][kt] = ld16_nt(src + kt * 32);
+  }
+  if (!full) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      if (arow0 + i * 16 + (lane & 15) >= a.M) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) areg[i][kt] = make_uint4(0, 0, 0, 0);
+      }
+  }
+  if constexpr (XF != 0) {
+    // normalise-on-load, once per element: act(x*xs + xt) — or, XF 2, the residual join act((x*xs + xt) + r(xb*xs2 + xt2))
+    // whose result (and 1-bit ReLU mask) is also handed back for the shortcut; maai_bn_act_fwd / _fwd2 arithmetic
+    uint4 breg[TM][XF == 2 ? KT : 1];
+    if constexpr (XF == 2) {
+      const T* __restrict__ xb = reinterpret_cast<const T*>(a.xb);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m = arow0 + i * 16 + (lane & 15);
+        const T* src = xb + (m < a.M ? m : a.M - 1) * KC + (lane >> 4) * 8;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) breg[i][kt] = ld16_nt(src + kt * 32);
+      }
+    }
+    __syncthreads();  // the coefficients are in LDS (no LDS-DMA is in flight yet)
+    const bool join2 = XF == 2 && a.xs2 != nullptr;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      float qs[8], qt[8], qs2[8], qt2[8];
+      const float* cs = xcoef + kt * 32 + (lane >> 4) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        qs[e] = cs[e];
+        qt[e] = cs[KC + e];
+      }
+      if (join2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          qs2[e] = cs[2 * KC + e];
+          qt2[e] = cs[3 * KC + e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m = arow0 + i * 16 + (lane & 15);
+        const bool ok = m < a.M;
+        Vec16<T> v, w2;
+        v.raw = areg[i][kt];
+        if constexpr (XF == 2) {
+          w2.raw = breg[i][kt];
+          const bool wb = a.x_out != nullptr && a.x_bits != nullptr;
+          const unsigned b = XfMath<T>::template run<true>(v, w2, qs, qt, join2 ? qs2 : nullptr, qt2, a.x_relu, wb);
+          if (ok && a.x_out) {
+            const long long goff = m * KC + kt * 32 + (lane >> 4) * 8;
+            v.store_nt(reinterpret_cast<T*>(a.x_out) + goff);
+            if (wb) a.x_bits[goff >> 3] = (unsigned char)b;
+          }
+        } else {
+          XfMath<T>::template run<false>(v, w2, qs, qt, nullptr, nullptr, a.x_relu, false);
+        }
+        areg[i][kt] = ok ? v.raw : make_uint4(0, 0, 0, 0);  // rows past the end stay zero
+      }
+    }
+  }
+
+  // ---- weight stages: stage s = (column tile s / KT, K-step s % KT), 64-byte rows, swizzled like conv_igemm ----
+  const int r0 = tid >> 2;
+  const int chunk = (tid & 3) ^ (((r0 >> 3) & 1) << 1);
+  const T* wsrc = w + (long long)r0 * KC + chunk * 8;   // next stage to issue: + (ict*BN + 64 i) * KC + ikt*32
+  int ikt = 0, islot = 0, issued = 0;
+  auto issue_b = [&]() {
+    char* sb = smem + islot * STAGE + widu * 1024;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) dma16<true>(wsrc + (long long)(64 * i) * KC, sb + i * 4096);
+    ++issued;
+    if (++islot == NSLOT) islot = 0;
+    if (++ikt == KT) {
+      ikt = 0;
+      wsrc += (long long)BN * KC - (KT - 1) * 32;
+    } else {
+      wsrc += 32;
+    }
+  };
+  const int pre = S < DIST ? S : DIST;
+  for (int s = 0; s < pre; ++s) issue_b();
+
+  const int frow = lane & 15;
+  const int foff = frow * 64 + (((lane >> 4) ^ (((frow >> 3) & 1) << 1)) << 4);
+  char* cw = smem + RING + widu * CW;      // this wave's private C area
+  const uint32_t cwa = (uint32_t)(uintptr_t)(cw + (((lane >> 4) * 4) * LDC + (lane & 15)) * 2);
+  float* sred = red + ((widu * 4 + (lane >> 4)) * 2) * BN + (lane & 15);
+
+  auto finish_stats = [&](int ct) {  // after a barrier that follows the epilogue of column tile ct
+    if (a.stats && EMODE != 6) {
+#pragma unroll
+      for (int o = tid; o < 2 * BN; o += 256) {
+        const int which = o / BN, c = o - which * BN;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[(k * 2 + which) * BN + c];
+        a.stats[((long long)mb * 2 + which) * a.Cout + ct * BN + c] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+
+  int s = 0, slot = 0;
+  for (int ct = 0; ct < nCT; ++ct) {
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      // ---- wait until weight stage s has landed.  Issued after it (in order): the DIST-1 following stages and the
+      // stores of every epilogue since — E of them, a function of (kt, ct); counting fewer than were issued only waits
+      // longer, so the store term is used for full tiles only (every wave then issues exactly NST stores per epilogue)
+      const int EMAX = (kt + 1 <= DIST) ? (DIST - 1 - kt) / KT + 1 : 0;   // (a constant once the loop is unrolled)
+      const int rem = S - 1 - s;
+      if (rem >= DIST - 1) {
+        const int E = full ? (ct < EMAX ? ct : EMAX) : 0;
+        if (E == 0) wait_vm<(DIST - 1) * BR>();
+        else if (E == 1) wait_vm<(DIST - 1) * BR + NST>();
+        else wait_vm<(DIST - 1) * BR + 2 * NST>();
+      } else if (rem == 1) {
+        wait_vm<BR>();
+      } else {
+        wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (issued < S) issue_b();   // into the slot of stage s-2
+      if (kt == 0 && ct > 0) finish_stats(ct - 1);
+      const char* sb = smem + slot * STAGE + foff;
+      frag_t bfr[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const frag_t*>(sb + j * 16 * 64);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const frag_t af = __builtin_bit_cast(frag_t, areg[i][kt]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::run(af, bfr[j], acc[i][j]);
+      }
+      ++s;
+      if (++slot == NSLOT) slot = 0;
+    }
+
+    // ---- epilogue of column tile ct: wave-private, no workgroup barrier ----
+    if (a.stats && EMODE != 6) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
+          s2 += lo;
+          q2 = __builtin_elementwise_fma(lo, lo, q2);
+          s2 += hi;
+          q2 = __builtin_elementwise_fma(hi, hi, q2);
+        }
+        sred[j * 16] = s2.x + s2.y;
+        sred[BN + j * 16] = q2.x + q2.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous group's reads of this area are done
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 v = acc[i][j];
+        const uint32_t p01 = pack_bf16x2(v[0], v[1]);
+        const uint32_t p23 = pack_bf16x2(v[2], v[3]);
+        asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(cwa), "v"(p01), "n"(j * 32),
+                     "n"(j * 32 + LDC * 2)
+                     : "memory");
+        asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(cwa), "v"(p23),
+                     "n"(j * 32 + LDC * 4), "n"(j * 32 + LDC * 6)
+                     : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long m0 = arow0 + i * 16 + lane / CPR;
+      T* dst = y + m0 * a.Cout + ct * BN + (lane % CPR) * 8;
+      const T* csrc = reinterpret_cast<const T*>(cw) + (lane / CPR) * LDC + (lane % CPR) * 8;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        Vec16<T> v;
+        v.load(csrc + it * RPI * LDC);
+        if (full || m0 + it * RPI < a.M) v.store(dst + (long long)it * RPI * a.Cout);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  finish_stats(nCT - 1);
+}
+
+template <int KC, int BN, int DIST, int XF, int EMODE>
+static int launch_pws(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds = (DIST + 2) * BN * 64 + 4 * 16 * (BN + 8) * 2 + 32 * BN * 4;
+  static_assert(4 * KC * 4 <= 4 * 16 * (BN + 8) * 2, "the coefficient table borrows the C area");
+  static int attr_lds[64] = {0};
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE>), lds, attr_lds);
+  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+template <int KC, int BN>
+static int pws_k(const ConvArgs& a, hipStream_t st) {
+  constexpr int DIST = KC == 256 ? 3 : 2;
+  if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
+  if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
+  return launch_pws<KC, BN, DIST, 0, 0>(a, st);
+}
+
+// one 128-row tile per workgroup (a.nMB = ceil(M / 128), the statistics slab's rows).  Column tile: 64 output channels
+// (4 workgroups per CU; 3 for Cin 256) except for Cin 256 with many output channels, where the MFMA share is large
+// enough for the 128-wide tile's fewer barriers to win (256->1024: 0.64 vs 0.67 ms).  MAAI_PWS_BN = 64 | 128 overrides.
+int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st) {
+  const char* e = getenv("MAAI_PWS_BN");   // experiment knob
+  const int forced = e ? atoi(e) : 0;
+  const bool n128 = a.Cout % 128 == 0 && forced != 64 && (forced == 128 || (a.Cin == 256 && a.Cout >= 512));
+  switch (a.Cin) {
+    case 64: return n128 ? pws_k<64, 128>(a, st) : pws_k<64, 64>(a, st);
+    case 128: return n128 ? pws_k<128, 128>(a, st) : pws_k<128, 64>(a, st);
+    case 256: return n128 ? pws_k<256, 128>(a, st) : pws_k<256, 64>(a, st);
+    default: break;
+  }
+  maai_set_error("conv2d_igemm: no streaming pointwise kernel for this channel count");
+  return MAAI_ERR_UNSUPPORTED;
+}

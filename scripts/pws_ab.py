@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Streaming pointwise kernel (conv_pws.hip) against the ring kernel (conv_igemm.h) on the benchmark's pointwise layer
+shapes: bit-identical outputs, statistics to fp32 rounding, interleaved timings.   python scripts/pws_ab.py [B]"""
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-active-ai_amd"))
+from maai_hip import kernels as K  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ROUNDS = 5
+
+
+ARMS = {"ring": {"MAAI_CONV_PWS": "0"}, "s128": {"MAAI_CONV_PWS": "2", "MAAI_PWS_BN": "128"}, "s64": {"MAAI_CONV_PWS": "2", "MAAI_PWS_BN": "64"}}
+
+
+def run(arm, fn):
+    os.environ.update(ARMS[arm])
+    return fn()
+
+
+def timeit(fn):
+    res = {k: [] for k in ARMS}
+    for p in ARMS:
+        run(p, fn)
+    torch.cuda.synchronize()
+    for _ in range(ROUNDS):
+        for p in ARMS:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(p, fn)
+            e1.record()
+            e1.synchronize()
+            res[p].append(e0.elapsed_time(e1))
+    return {k: statistics.median(v) for k, v in res.items()}
+
+
+def case(hw, cin, cout, lazy):
+    n = B
+    x = torch.randn(n, hw, hw, cin, device="cuda").bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, device="cuda") / cin ** 0.5).bfloat16()
+    s, t = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3
+    inp = K.Lazy(x, s, t, True) if lazy else x
+    fn = lambda: K.conv2d(inp, w, 1, 0, 0, stats=True)
+    y0, st0 = run("ring", fn)
+    same, serr = True, 0.0
+    for arm in ("s128", "s64") * 3:
+        y1, st1 = run(arm, fn)
+        torch.cuda.synchronize()
+        same &= torch.equal(y0, y1)
+        # the slabs have one row per tile (the two kernels may tile differently): compare the column totals
+        t0s, t1s = st0.double().sum(0), st1.double().sum(0)
+        serr = max(serr, float(((t0s - t1s).abs() / (t0s.abs() + 1e-6 * t0s.abs().max())).max()))
+    r = timeit(fn)
+    by = 2.0 * n * hw * hw * (cin + cout)
+    print("%4d->%4d @%3d %s  " % (cin, cout, hw, "lazy " if lazy else "plain") +
+          "  ".join("%s %6.3f ms (%4.0f GB/s)" % (k, v, by / v / 1e6) for k, v in r.items()) +
+          "   best stream %+5.1f %%   y identical: %s  stats rel %.1e" % ((r["ring"] / min(r["s128"], r["s64"]) - 1) * 100, same, serr), flush=True)
+    return same
+
+
+if __name__ == "__main__":
+    print("B = %d" % B)
+    ok = True
+    for lazy in (False, True):
+        for hw, cin, cout in ((224, 64, 64), (224, 64, 256), (112, 128, 512), (112, 128, 128), (56, 256, 1024), (56, 256, 256), (56, 256, 512),
+                              (224, 256, 64), (112, 256, 128)):
+            ok &= case(hw, cin, cout, lazy)
+    print("all identical" if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)

@@ -1,0 +1,127 @@
+"""The streaming pointwise kernel (csrc/conv_pws.hip: A operand in registers, weights streamed through LDS, all column
+tiles per workgroup) against the ring kernel (csrc/conv_igemm.h), which test_gpu_kernels.py pins to the oracle: the same
+MFMA sequence per output element, so outputs must be bit-identical — plain and normalise-on-load inputs, both column
+tiles, rows beyond M, one to many column tiles — and the BatchNorm statistics slab (one row per 128 pixels in both) must
+agree to fp32 summation order.  Reference semantics: resnet.py:101-109 (conv1 / conv3 of a bottleneck)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    from maai_hip import kernels
+    return kernels
+
+
+class env(object):
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# N, H, W, Cin, Cout
+CASES = [
+    (2, 30, 30, 64, 256),     # conv3 of layer 1 (two K-steps per column tile: the densest epilogue / prefetch interleave)
+    (2, 30, 30, 64, 64),      # ONE column tile, fewer weight stages than ring slots
+    (3, 15, 15, 128, 512),    # M = 675: rows beyond M in the last tile
+    (1, 9, 11, 128, 128),     # M = 99 < one tile
+    (2, 16, 16, 256, 1024),   # layer 3: eight K-steps, eight / sixteen column tiles
+    (2, 12, 12, 256, 64),     # channel-reducing (kernel is built for it; the shape rule keeps the ring kernel)
+    (5, 7, 9, 256, 192),      # Cout not a multiple of 128
+    (1, 56, 56, 128, 512),    # many row tiles
+]
+
+
+def _run(K, x, w, lazy):
+    return K.conv2d(K.Lazy(*lazy) if lazy else x, w, 1, 0, 0, stats=True)
+
+
+@pytest.mark.parametrize("bn", ["64", "128"])
+@pytest.mark.parametrize("mode", ["plain", "relu", "lin"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_streaming_pointwise_matches_ring_kernel(K, case, mode, bn):
+    n, h, w_, cin, cout = case
+    g = torch.Generator().manual_seed(hash(case) % 10007)
+    x = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda().bfloat16()
+    lazy = None
+    if mode != "plain":
+        s = ((torch.rand(cin, generator=g) * 1.5 + 0.25) * torch.where(torch.rand(cin, generator=g) < 0.2, -1.0, 1.0)).cuda()
+        t = (torch.randn(cin, generator=g) * 0.7).cuda()
+        lazy = (x, s, t, mode == "relu")
+    with env(MAAI_CONV_PWS="0"):
+        y0, st0 = _run(K, x, w, lazy)
+    with env(MAAI_CONV_PWS="2", MAAI_PWS_BN=bn):
+        y1, st1 = _run(K, x, w, lazy)
+        y2, st2 = _run(K, x, w, lazy)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), "streaming kernel output differs from the ring kernel's"
+    assert torch.equal(y1, y2) and torch.equal(st1, st2), "streaming kernel is not deterministic"
+    m = n * h * w_
+    assert st1.shape == ((m + 127) // 128, 2, cout)
+    t0, t1 = st0.double().sum(0), st1.double().sum(0)
+    # sums of ~m fp32 terms in two different orders
+    tol = 2e-6 * (st0.double().abs().sum(0) + 1.0)
+    assert bool(((t0 - t1).abs() <= tol).all()), float(((t0 - t1).abs() / tol).max())
+    # the slab's rows are per-tile sums of the (fp32) accumulators: check one tile against the stored bf16 output
+    rows = min(128, m)
+    ref = y1.reshape(m, cout)[:rows].double().sum(0)
+    assert torch.allclose(st1[0, 0].double(), ref, rtol=0, atol=0.02 * rows ** 0.5 + 0.01 * float(ref.abs().max()))
+
+
+def test_shape_rule_and_knob_precedence(K):
+    """expanding layers take the streaming kernel by default (slab rows = M/128 either way), a forced ring tile wins"""
+    x = torch.randn(2, 32, 32, 256).cuda().bfloat16()
+    w = (torch.randn(1024, 1, 1, 256) / 16).cuda().bfloat16()
+    with env(MAAI_CONV_PWS="0"):
+        y0, st0 = K.conv2d(x, w, stats=True)
+    y1, st1 = K.conv2d(x, w, stats=True)                    # default: streaming
+    with env(MAAI_CONV_BN="256"):
+        y2, st2 = K.conv2d(x, w, stats=True)                # forced 128x256 ring tile
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    assert st0.shape == st1.shape == st2.shape == (16, 2, 1024)
+    assert torch.equal(st0, st2) and not torch.equal(st0, st1)   # the two kernels sum the rows of a tile in different orders
+
+
+@pytest.mark.parametrize("bn", ["64", "128"])
+@pytest.mark.parametrize("shortcut", ["identity", "projection"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (3, 15, 15, 256, 64), (1, 9, 11, 128, 128), (2, 12, 12, 256, 1024)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_streaming_join_on_load_matches_ring_kernel(K, case, shortcut, bn):
+    """the residual join relu(bn3(y3) + shortcut) formed on load (resnet.py:126-133): output, joined tensor, 1-bit mask"""
+    n, h, w_, cin, cout = case
+    g = torch.Generator().manual_seed(hash(case) % 10007 + 1)
+    y3 = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    sc = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda().bfloat16()
+    s, t = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.5).cuda()
+    if shortcut == "projection":
+        s2, t2 = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.5).cuda()
+        lazy = K.Lazy(y3, s, t, True, sc, s2, t2)
+    else:
+        lazy = K.Lazy(y3, s, t, True, sc.clamp_min(0))
+    res = []
+    for kv in ({"MAAI_CONV_PWS": "0"}, {"MAAI_CONV_PWS": "2", "MAAI_PWS_BN": bn}):
+        with env(**kv):
+            res.append(K.conv2d(lazy, w, stats=True, join_out=True, join_bits=True))
+    torch.cuda.synchronize()
+    (y0, st0, j0, b0), (y1, st1, j1, b1) = res
+    assert torch.equal(y0, y1) and torch.equal(j0, j1) and torch.equal(b0, b1)
+    t0, t1 = st0.double().sum(0), st1.double().sum(0)
+    assert bool(((t0 - t1).abs() <= 2e-6 * (st0.double().abs().sum(0) + 1.0)).all())
