@@ -492,14 +492,17 @@ struct WgradPatchArgs {
   int x_relu;
 };
 
-template <bool XF>
-__global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a) {
+// DB: two patch buffers (92 KB, one workgroup per CU): the next patch's LDS-DMA is issued right after the barrier that
+// opens the multiply phase of the current one, and lands (and, XF, is normalised by its owner lanes) behind its MFMAs —
+// one barrier per patch instead of two, no exposed load latency.  The DMA is inline assembly there: hipcc would order
+// the fragment reads behind every LDS-DMA in flight.
+template <bool XF, bool DB>
+__global__ __launch_bounds__(384, DB ? 2 : 3) void wgrad3x3_patch_kernel(WgradPatchArgs a) {
   constexpr int TH = 8, HW = 24, RB = 128;            // patch rows, halo slots per row, bytes per pixel row (64 ch)
   constexpr int YB = TH * 16 * RB;                    // dY tile bytes (16 KB)
   constexpr int NIY = YB / 1024, NIH = (TH + 2) * HW * RB / 1024;  // wave-wide DMA instructions: 16 + 30
+  constexpr int PB = YB + (TH + 2) * HW * RB;        // bytes of one patch buffer (46 KB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ybuf = smem;
-  char* hbuf = smem + YB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int widu = __builtin_amdgcn_readfirstlane(wid);
   const int half = widu / 3, kh = widu - half * 3;
@@ -566,12 +569,12 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
   // has no room for them
   const int xf_c = ci0 + (dch ^ (((drow >> 1) & 3) << 1)) * 8;
 
-  for (long long pt = p_begin; pt < p_end; ++pt) {
+  // stage patch pt (dY tile + input halo) into buffer ybuf / hbuf
+  auto issue_patch = [&](long long pt, char* ybuf, char* hbuf) {
     const int n = (int)(pt / tpi);
     const int rem = (int)(pt - (long long)n * tpi);
     const int tyi = rem / a.tilesX;
     const int oy0 = tyi * TH, ox0 = (rem - tyi * a.tilesX) * 16;
-    __syncthreads();  // everyone is done multiplying the previous patch
     if (oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + 17 <= a.W) {
       const long long pix0 = ((long long)n * a.H + oy0) * a.W + ox0;
       const bf16_t* by = dy + pix0 * a.Cout;
@@ -580,12 +583,10 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
       for (int i = 0; i < NDI; ++i) {
         const int qi = widu + 6 * i;
         if (qi < NIY) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(by + rel[i]),
-                                           (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
+          wdma16<DB>(by + rel[i], ybuf + qi * 1024);
         } else if (qi < NIY + NIH) {
           const bf16_t* src = ((padmask >> i) & 1u) ? zsrc : bx + rel[i];
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+          wdma16<DB>(src, hbuf + (qi - NIY) * 1024);
         }
       }
     } else {
@@ -597,8 +598,7 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
           const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
           const int sc = dch ^ (((row >> 1) & 3) << 1);
           const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + sc * 8 : zsrc;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(ybuf + qi * 1024), 16, 0, 0);
+          wdma16<DB>(src, ybuf + qi * 1024);
         } else if (qi < NIY + NIH) {
           const int hp = (qi - NIY) * 8 + drow;  // halo slot
           const int hy = hp / HW, hx = hp - hy * HW;
@@ -606,40 +606,85 @@ __global__ __launch_bounds__(384, 3) void wgrad3x3_patch_kernel(WgradPatchArgs a
           const int sc = dch ^ (((hp >> 1) & 3) << 1);
           const bool ok = hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
           const bf16_t* src = ok ? x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + sc * 8 : zsrc;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(hbuf + (qi - NIY) * 1024), 16, 0, 0);
+          wdma16<DB>(src, hbuf + (qi - NIY) * 1024);
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (XF) {
-      // normalise (+ activate) this lane's own halo chunks in place; padding (zero page) stays zero
-      float xcs[8], xct[8];
+  };
+  // (the double-buffered kernel runs at two waves per SIMD: its 256-register budget holds the coefficients for good)
+  float hcs[8], hct[8];
+  if constexpr (XF && DB) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xcs[e] = a.xs[xf_c + e];
-        xct[e] = a.xt[xf_c + e];
-      }
+    for (int e = 0; e < 8; ++e) {
+      hcs[e] = a.xs[xf_c + e];
+      hct[e] = a.xt[xf_c + e];
+    }
+  }
+  // XF: normalise (+ activate) this lane's own halo chunks of patch pt in place; padding (zero page) stays zero
+  auto xform_patch = [&](long long pt, char* hbuf) {
+    const int n = (int)(pt / tpi);
+    const int rem = (int)(pt - (long long)n * tpi);
+    const int tyi = rem / a.tilesX;
+    const int oy0 = tyi * TH, ox0 = (rem - tyi * a.tilesX) * 16;
+    float xcs[8], xct[8];
 #pragma unroll
-      for (int i = 0; i < NDI; ++i) {
-        const int qi = widu + 6 * i;
-        if (qi >= NIY && qi < NIY + NIH) {
-          const int hp = (qi - NIY) * 8 + drow;
-          const int hy = hp / HW, hx = hp - hy * HW;
-          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-          if (hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-            bf16_t* p = reinterpret_cast<bf16_t*>(hbuf + (qi - NIY) * 1024 + lane * 16);
-            Vec16<bf16_t> v;
-            v.load(p);
-            xf_apply<bf16_t>(v, xcs, xct, a.x_relu);
-            v.store(p);
-          }
+    for (int e = 0; e < 8; ++e) {
+      xcs[e] = DB ? hcs[e] : a.xs[xf_c + e];
+      xct[e] = DB ? hct[e] : a.xt[xf_c + e];
+    }
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int qi = widu + 6 * i;
+      if (qi >= NIY && qi < NIY + NIH) {
+        const int hp = (qi - NIY) * 8 + drow;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+        if (hx < 18 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+          bf16_t* p = reinterpret_cast<bf16_t*>(hbuf + (qi - NIY) * 1024 + lane * 16);
+          Vec16<bf16_t> v;
+          v.load(p);
+          xf_apply<bf16_t>(v, xcs, xct, a.x_relu);
+          v.store(p);
         }
       }
     }
-    __syncthreads();
+  };
+
+  if constexpr (DB) {
+    if (p_begin < p_end) issue_patch(p_begin, smem, smem + YB);
+  }
+  for (long long pt = p_begin; pt < p_end; ++pt) {
+    char* ybuf = smem + (DB ? (int)((pt - p_begin) & 1) * PB : 0);
+    char* hbuf = ybuf + YB;
+    if constexpr (DB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's chunks of patch pt have landed
+      if constexpr (XF) {
+        if (pt == p_begin) xform_patch(pt, hbuf);        // (later patches were normalised inside the previous multiply phase)
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();  // patch pt is complete in LDS; everyone is done multiplying patch pt-1
+      if (pt + 1 < p_end) {
+        char* yn = smem + (int)((pt + 1 - p_begin) & 1) * PB;
+        issue_patch(pt + 1, yn, yn + YB);
+      }
+    } else {
+      __syncthreads();  // everyone is done multiplying the previous patch
+      issue_patch(pt, ybuf, hbuf);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (XF) xform_patch(pt, hbuf);
+      __syncthreads();
+    }
 #pragma unroll
     for (int s = 0; s < TH / 2; ++s) {
+      if constexpr (XF && DB) {
+        // before the last K-step: the next patch has had three steps to land; its owner lanes normalise it while the
+        // other wave of the SIMD keeps the matrix pipe busy
+        if (s == TH / 2 - 1 && pt + 1 < p_end) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          xform_patch(pt + 1, smem + (int)((pt + 1 - p_begin) & 1) * PB + YB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       bf16x8 af[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -714,14 +759,29 @@ static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
   if (split < 1) split = 1;
   a.per_split = (a.npatch + split - 1) / split;
   split = (a.npatch + a.per_split - 1) / a.per_split;
-  constexpr int lds = 8 * 16 * 128 + 10 * 24 * 128;  // 16 KB + 30 KB
-  static int attr_a[64] = {0}, attr_b[64] = {0};
-  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false>), lds, attr_a);
-  maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true>), lds, attr_b);
-  if (a.xs)
-    hipLaunchKernelGGL(wgrad3x3_patch_kernel<true>, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
-  else
-    hipLaunchKernelGGL(wgrad3x3_patch_kernel<false>, dim3((unsigned)(tiles * split)), dim3(384), lds, st, a);
+  constexpr int lds1 = 8 * 16 * 128 + 10 * 24 * 128;  // 16 KB + 30 KB per patch buffer
+  const char* e = getenv("MAAI_WGRAD_PATCH_DB");         // 0: the single-buffered kernel (two workgroups per CU), for A/B runs
+  const bool db = !(e && atoi(e) == 0);
+  const int lds = db ? 2 * lds1 : lds1;
+  static int attr[4][64] = {{0}};
+  const dim3 grid((unsigned)(tiles * split));
+  if (a.xs) {
+    if (db) {
+      maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true, true>), lds, attr[0]);
+      hipLaunchKernelGGL((wgrad3x3_patch_kernel<true, true>), grid, dim3(384), lds, st, a);
+    } else {
+      maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true, false>), lds, attr[1]);
+      hipLaunchKernelGGL((wgrad3x3_patch_kernel<true, false>), grid, dim3(384), lds, st, a);
+    }
+  } else {
+    if (db) {
+      maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false, true>), lds, attr[2]);
+      hipLaunchKernelGGL((wgrad3x3_patch_kernel<false, true>), grid, dim3(384), lds, st, a);
+    } else {
+      maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false, false>), lds, attr[3]);
+      hipLaunchKernelGGL((wgrad3x3_patch_kernel<false, false>), grid, dim3(384), lds, st, a);
+    }
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

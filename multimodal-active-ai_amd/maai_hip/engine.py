@@ -306,7 +306,9 @@ def _lazy_pays(consumers, keep):
     for conv in consumers:
         k, cin, stride = conv.kernel_size[0], conv.in_channels, conv.stride[0]
         if k == 1:
-            ok = cin <= (64 if keep else 128)
+            # (the streaming kernel normalises once per element: free for the expanding layers it takes, up to 256 channels;
+            #  with a backward pass the weight gradient would pay for it instead)
+            ok = cin <= (64 if keep else 128) or (not keep and cin <= 256 and stride == 1 and conv.out_channels >= 2 * cin)
         elif k == 3:
             ok = (not keep) and (cin <= 64 or (stride == 2 and cin <= 128))
         else:

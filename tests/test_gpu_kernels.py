@@ -214,10 +214,11 @@ def test_wgrad_exact_integer_layout(K):
 
 @pytest.mark.parametrize("case", [(2, 64, 30, 30, 64), (1, 128, 16, 16, 64), (3, 64, 13, 11, 128), (2, 128, 40, 24, 192),
                                   (1, 64, 8, 16, 64), (5, 192, 9, 7, 64)])
-def test_wgrad3x3_patch_kernel(K, case):
-    """The patch-staged 3x3 weight gradient (normally chosen by shape, forced on here): against autograd in fp64
-    on random bf16 data, and bit-for-bit on integer data (exact in any order) — full, ragged and tiny planes,
-    several (co, ci) tiles, more splits than patches."""
+@pytest.mark.parametrize("db", ["1", "0"], ids=["double-buffered", "single-buffered"])
+def test_wgrad3x3_patch_kernel(K, case, db):
+    """The patch-staged 3x3 weight gradient (normally chosen by shape, forced on here; both buffering schemes):
+    against autograd in fp64 on random bf16 data, and bit-for-bit on integer data (exact in any order) — full, ragged
+    and tiny planes, several (co, ci) tiles, more splits than patches."""
     n, cin, h, w, cout = case
     g = torch.Generator().manual_seed(55 + h + cin)
     x, dy = rb(torch.randn(n, cin, h, w, generator=g)), rb(torch.randn(n, cout, h, w, generator=g))
@@ -227,17 +228,19 @@ def test_wgrad3x3_patch_kernel(K, case):
     dyi = torch.randint(-2, 3, (n, cout, h, w), generator=g).float()
     wi = torch.zeros(cout, cin, 3, 3, requires_grad=True)
     F.conv2d(xi, wi, None, 1, 1).backward(dyi)
-    old = os.environ.get("MAAI_WGRAD_PATCH")
+    old = {k: os.environ.get(k) for k in ("MAAI_WGRAD_PATCH", "MAAI_WGRAD_PATCH_DB")}
     os.environ["MAAI_WGRAD_PATCH"] = "1"
+    os.environ["MAAI_WGRAD_PATCH_DB"] = db
     try:
         dw = K.conv2d_wgrad(nhwc(x, torch.bfloat16), nhwc(dy, torch.bfloat16), 3, 3, 1, 1, 1)
         dwi = K.conv2d_wgrad(nhwc(xi, torch.bfloat16), nhwc(dyi, torch.bfloat16), 3, 3, 1, 1, 1)
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            os.environ.pop("MAAI_WGRAD_PATCH", None)
-        else:
-            os.environ["MAAI_WGRAD_PATCH"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     scale = wt.grad.abs().max().item()
     np.testing.assert_allclose(dw.cpu().permute(0, 3, 1, 2).numpy(), wt.grad.float().numpy(), rtol=1e-4, atol=2e-5 * scale + 1e-5)
     assert torch.equal(dwi.cpu().permute(0, 3, 1, 2), wi.grad)

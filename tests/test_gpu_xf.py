@@ -158,13 +158,13 @@ WGRAD_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
-@pytest.mark.parametrize("patch", ["0", "1"], ids=["ring", "patch"])
+@pytest.mark.parametrize("patch", ["0", "1", "1s"], ids=["ring", "patch", "patch-single-buffered"])
 @pytest.mark.parametrize("case", WGRAD_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_wgrad_lazy_input_exact(K, case, patch, dtype):
     """Weight gradient with the activation formed on load.  Integer data (every product and partial sum exact in
     fp32, whatever the order of the atomic adds): bit-identical to the materialised path and to fp64 autograd."""
     n, cin, h, w, cout, k, stride, pad = case
-    if patch == "1" and not (k == 3 and stride == 1 and dtype == torch.bfloat16):
+    if patch != "0" and not (k == 3 and stride == 1 and dtype == torch.bfloat16):
         pytest.skip("patch-staged kernel: bf16 3x3 stride 1")
     g = torch.Generator().manual_seed(5 + cin + h)
     y = torch.randint(-6, 7, (n, h, w, cin), generator=g).float()
@@ -173,7 +173,7 @@ def test_wgrad_lazy_input_exact(K, case, patch, dtype):
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     dy = torch.randint(-2, 3, (n, oh, ow, cout), generator=g).float()
     yd, dyd, sc, sh = y.to(dtype).cuda(), dy.to(dtype).cuda(), scale.cuda(), shift.cuda()
-    with env(MAAI_WGRAD_PATCH=patch, MAAI_AUTOTUNE="0"):
+    with env(MAAI_WGRAD_PATCH=patch[0], MAAI_WGRAD_PATCH_DB="0" if patch == "1s" else "1", MAAI_AUTOTUNE="0"):
         K.AUTOTUNE[0] = False
         try:
             act = K.bn_act_fwd(yd, sc, sh, None, True)
