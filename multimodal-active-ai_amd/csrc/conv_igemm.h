@@ -864,3 +864,4 @@ struct ConvSel {
 int maai_conv_xf_launch(const ConvArgs& a, const ConvSel& sel, hipStream_t st);
 // conv_pws.hip: the streaming kernel for pointwise layers with Cin <= 256 (A operand in registers, weights streamed)
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st);
+int maai_conv_pws_tile_rows(int cin);

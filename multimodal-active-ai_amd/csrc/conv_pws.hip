@@ -25,10 +25,11 @@ __device__ __forceinline__ void wait_vm() {
 // barrier of step s-1 — safe wherever the compiler schedules the MFMAs of step s-1 around the barrier of step s (the
 // K loop is fully unrolled here and hipcc does sink them below it, with their fragment reads still outstanding).
 // EMODE 0: plain store (+ statistics slab); 5: accumulate and/or ReLU mask; 6: 5 + BN-backward sums (DGRAD_REDUCE).
-template <int KC, int BN, int DIST, int XF, int EMODE>
-__global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
+// TM = 16-row MFMA tiles per wave: 2 (128-row workgroup tile), or 1 (64 rows) for Cin 512, whose K extent fills the registers.
+template <int KC, int BN, int DIST, int XF, int EMODE, int TM = 2>
+__global__ __launch_bounds__(256, KC == 512 ? 2 : (BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4))) void conv_pws_kernel(ConvArgs a) {
   typedef bf16_t T;
-  constexpr int TM = 2, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
+  constexpr int BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
   constexpr int LDC = BN + 8;              // private C tile row pitch (elements)
   constexpr int CW = 16 * LDC * 2;         // bytes of one wave's 16-row C area
   constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
   const int nCT = a.Cout / BN;
   const int S = nCT * KT;                  // weight stages of this workgroup
-  const bool full = (long long)(mb + 1) * 128 <= a.M;
+  const bool full = (long long)(mb + 1) * BM <= a.M;
 
   if constexpr (XF != 0) {
     const int nco = (XF == 2 && a.xs2) ? 4 * KC : 2 * KC;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   }
 
   // ---- the A operand: rows mb*128 + wid*32 + i*16 + (lane & 15), channels kt*32 + (lane >> 4)*8 .. +8 ----
-  const long long arow0 = (long long)mb * 128 + widu * 32;
+  const long long arow0 = (long long)mb * BM + widu * (16 * TM);
   uint4 areg[TM][KT];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -265,36 +266,47 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   finish_stats(nCT - 1);
 }
 
-template <int KC, int BN, int DIST, int XF, int EMODE>
-static int launch_pws(const ConvArgs& a, hipStream_t st) {
+template <int KC, int BN, int DIST, int XF, int EMODE, int TM = 2>
+static int launch_pws(ConvArgs a, hipStream_t st) {
   constexpr int lds = (DIST + 2) * BN * 64 + 4 * 16 * (BN + 8) * 2 + 32 * BN * 4;
   static_assert(4 * KC * 4 <= 4 * 16 * (BN + 8) * 2, "the coefficient table borrows the C area");
+  a.nMB = (int)((a.M + 64 * TM - 1) / (64 * TM));
   static int attr_lds[64] = {0};
-  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE>), lds, attr_lds);
-  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, TM>), lds, attr_lds);
+  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, TM>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
 
 template <int KC, int BN>
 static int pws_k(const ConvArgs& a, hipStream_t st) {
-  constexpr int DIST = KC == 256 ? 3 : 2;
-  if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
-  if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
-  return launch_pws<KC, BN, DIST, 0, 0>(a, st);
+  constexpr int DIST = KC >= 256 ? 3 : 2;
+  if constexpr (KC == 512) {  // the two-tensor join of layer 2 (the only launches this wide that are HBM-bound enough)
+    if (a.xb) return launch_pws<KC, BN, DIST, 2, 0, 1>(a, st);
+    maai_set_error("conv2d_igemm: the 512-channel streaming kernel is built for the join on load");
+    return MAAI_ERR_UNSUPPORTED;
+  } else {
+    if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
+    if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
+    return launch_pws<KC, BN, DIST, 0, 0>(a, st);
+  }
 }
 
-// one 128-row tile per workgroup (a.nMB = ceil(M / 128), the statistics slab's rows).  Column tile: 64 output channels
-// (4 workgroups per CU; 3 for Cin 256) except for Cin 256 with many output channels, where the MFMA share is large
-// enough for the 128-wide tile's fewer barriers to win (256->1024: 0.64 vs 0.67 ms).  MAAI_PWS_BN = 64 | 128 overrides.
+// rows of the output (= of the statistics slab) per workgroup
+int maai_conv_pws_tile_rows(int cin) { return cin == 512 ? 64 : 128; }
+
+// One row tile per workgroup.  Column tile: 64 output channels (4 workgroups per CU; 3 for Cin 256) except for Cin >= 256
+// with many output channels, where the MFMA share is large enough for the 128-wide tile's fewer barriers to win
+// (256->1024: 0.64 vs 0.67 ms).  MAAI_PWS_BN = 64 | 128 overrides.
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st) {
   const char* e = getenv("MAAI_PWS_BN");   // experiment knob
   const int forced = e ? atoi(e) : 0;
-  const bool n128 = a.Cout % 128 == 0 && forced != 64 && (forced == 128 || (a.Cin == 256 && a.Cout >= 512));
+  const bool n128 = a.Cout % 128 == 0 && forced != 64 && (forced == 128 || (a.Cin >= 256 && a.Cout >= 512));
   switch (a.Cin) {
     case 64: return n128 ? pws_k<64, 128>(a, st) : pws_k<64, 64>(a, st);
     case 128: return n128 ? pws_k<128, 128>(a, st) : pws_k<128, 64>(a, st);
     case 256: return n128 ? pws_k<256, 128>(a, st) : pws_k<256, 64>(a, st);
+    case 512: return n128 ? pws_k<512, 128>(a, st) : pws_k<512, 64>(a, st);
     default: break;
   }
   maai_set_error("conv2d_igemm: no streaming pointwise kernel for this channel count");

@@ -63,9 +63,37 @@ def case(hw, cin, cout, lazy):
     return same
 
 
+def join_case(hw, cin, cout, proj):
+    n = B
+    y3 = torch.randn(n, hw, hw, cin, device="cuda").bfloat16()
+    sc = torch.randn(n, hw, hw, cin, device="cuda").bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, device="cuda") / cin ** 0.5).bfloat16()
+    s, t = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3
+    lazy = K.Lazy(y3, s, t, True, sc, s + 0.1, t - 0.1) if proj else K.Lazy(y3, s, t, True, sc.clamp_min(0))
+    fn = lambda: K.conv2d(lazy, w, stats=True, join_out=True, join_bits=True)
+    r0 = run("ring", fn)
+    same = True
+    for arm in ("s128", "s64") * 2:
+        r1 = run(arm, fn)
+        torch.cuda.synchronize()
+        same &= torch.equal(r0[0], r1[0]) and torch.equal(r0[2], r1[2]) and torch.equal(r0[3], r1[3])
+    r = timeit(fn)
+    by = 2.0 * n * hw * hw * (3 * cin + cout)
+    print("join %4d->%4d @%3d %s  " % (cin, cout, hw, "proj" if proj else "iden") +
+          "  ".join("%s %6.3f ms (%4.0f GB/s)" % (k, v, by / v / 1e6) for k, v in r.items()) +
+          "   best stream %+5.1f %%   identical: %s" % ((r["ring"] / min(r["s128"], r["s64"]) - 1) * 100, same), flush=True)
+    return same
+
+
 if __name__ == "__main__":
     print("B = %d" % B)
     ok = True
+    if len(sys.argv) > 2 and sys.argv[2] == "join":
+        for hw, cin, cout, proj in ((112, 512, 128, False), (112, 512, 256, False), (112, 512, 128, True), (224, 256, 64, False), (224, 256, 128, False),
+                                    (56, 512, 256, False)):
+            ok &= join_case(hw, cin, cout, proj)
+        print("all identical" if ok else "MISMATCH")
+        sys.exit(0 if ok else 1)
     for lazy in (False, True):
         for hw, cin, cout in ((224, 64, 64), (224, 64, 256), (112, 128, 512), (112, 128, 128), (56, 256, 1024), (56, 256, 256), (56, 256, 512),
                               (224, 256, 64), (112, 256, 128)):

@@ -101,7 +101,8 @@ def test_shape_rule_and_knob_precedence(K):
 
 @pytest.mark.parametrize("bn", ["64", "128"])
 @pytest.mark.parametrize("shortcut", ["identity", "projection"])
-@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (3, 15, 15, 256, 64), (1, 9, 11, 128, 128), (2, 12, 12, 256, 1024)],
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (3, 15, 15, 256, 64), (1, 9, 11, 128, 128), (2, 12, 12, 256, 1024),
+                                  (2, 12, 12, 512, 128), (1, 9, 11, 512, 256), (3, 8, 8, 512, 64)],   # 512: 64-row tiles
                          ids=lambda c: "x".join(map(str, c)))
 def test_streaming_join_on_load_matches_ring_kernel(K, case, shortcut, bn):
     """the residual join relu(bn3(y3) + shortcut) formed on load (resnet.py:126-133): output, joined tensor, 1-bit mask"""
@@ -123,5 +124,8 @@ def test_streaming_join_on_load_matches_ring_kernel(K, case, shortcut, bn):
     torch.cuda.synchronize()
     (y0, st0, j0, b0), (y1, st1, j1, b1) = res
     assert torch.equal(y0, y1) and torch.equal(j0, j1) and torch.equal(b0, b1)
+    m = n * h * w_
+    rows = 64 if cin == 512 else 128
+    assert st1.shape == ((m + rows - 1) // rows, 2, cout)
     t0, t1 = st0.double().sum(0), st1.double().sum(0)
     assert bool(((t0 - t1).abs() <= 2e-6 * (st0.double().abs().sum(0) + 1.0)).all())
