@@ -28,7 +28,7 @@ extern "C" {
 #define MAAI_BF16 0
 #define MAAI_F32 1
 
-#define MAAI_ABI_VERSION 2
+#define MAAI_ABI_VERSION 3
 
 int maai_abi_version(void);
 const char* maai_last_error(void);
@@ -136,6 +136,21 @@ typedef struct {
   const float* xt2;
   void* x_out;
   unsigned char* x_bits;
+  /* Chained launch (bf16, pointwise, with the two-tensor join above; resnet.py:118-133 + :101 of the next block): x is
+   * not read at all.  It is RECOMPUTED as the pointwise convolution  conv(a, pre_w)  of pre_x [M][pre_cin] (a = pre_x, or
+   * act(pre_x*pre_xs + pre_xt) when pre_xs is given: normalise-on-load of conv3's own input) with pre_w [Cin][pre_cin],
+   * rounded to the storage type exactly as the launch that would have stored it; (xs, xt) are then the BatchNorm
+   * coefficients of that recomputed tensor — whose batch statistics the caller has taken with a MAAI_EPI_STATS_ONLY
+   * launch of the same convolution — and the join, x_out, x_bits and this convolution proceed as above, bit-identical to
+   * the unchained sequence.  pre_y_out (nullable, [M][Cin]) receives the recomputed tensor when the backward pass needs
+   * it.  Built for pre_cin = 64, Cin = 256; x_out is required.  NULL pre_x = not chained. */
+  const void* pre_x;
+  const void* pre_w;
+  const float* pre_xs;
+  const float* pre_xt;
+  int pre_relu;
+  int pre_cin;
+  void* pre_y_out;
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);

@@ -169,13 +169,13 @@ static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
   const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
   if (!(dtype == MAAI_BF16 && pw1 && d->Cout % 64 == 0)) return false;
   if (d->accumulate || d->out_stride != 1 || d->OH != d->OHg || d->OW != d->OWg) return false;
-  if (epi && (epi->mode != MAAI_EPI_STORE || epi->a2)) return false;
-  // 512 input channels: the residual join feeding a layer with several column tiles only — both operands are then
-  // normalised ONCE instead of once per column tile (512->256@112: 3.59 -> 3.16 ms; 512->128 loses 8 %).  64-row tiles:
-  // the K extent fills the registers
-  if (d->Cin == 512) return epi && epi->xb && (mode == 2 || d->Cout >= 256);
+  if (epi && ((epi->mode != MAAI_EPI_STORE && !(epi->mode == MAAI_EPI_STATS_ONLY && !epi->xb)) || epi->a2 || epi->pre_x)) return false;
   if (!(d->Cin == 64 || d->Cin == 128 || d->Cin == 256)) return false;
-  return mode == 2 || d->Cout >= 2 * d->Cin;
+  // ... and every forward launch with 256 input channels (conv1 of layer 1's blocks and of layer2.0: 1-7 % slower than the
+  // ring kernel there): the chained launch of conv_chain.hip, which replaces the join-on-load form of those launches in
+  // forwards without a backward pass, adds the statistics of ITS output in the streaming kernel's order, and plain, joined
+  // and chained boundaries must all give the same slab bit for bit
+  return mode == 2 || d->Cout >= 2 * d->Cin || d->Cin == 256;
 }
 
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
@@ -186,7 +186,7 @@ extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const v
 extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                        const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream) {
   const int emode = epi ? epi->mode : MAAI_EPI_STORE;
-  MAAI_CHECK_ARG(d && x && w, "conv2d_igemm: null pointer");
+  MAAI_CHECK_ARG(d && w && (x || (epi && epi->pre_x)), "conv2d_igemm: null pointer");
   MAAI_CHECK_ARG(emode >= 0 && emode <= MAAI_EPI_DGRAD_REDUCE, "conv2d_igemm: bad epilogue mode");
   MAAI_CHECK_ARG(y || emode == MAAI_EPI_STATS_ONLY || emode == MAAI_EPI_BWD_REDUCE, "conv2d_igemm: null output");
   MAAI_CHECK_ARG((emode != MAAI_EPI_STATS_ONLY && emode != MAAI_EPI_BWD_REDUCE && emode != MAAI_EPI_DGRAD_REDUCE) || stats_partial, "conv2d_igemm: this epilogue needs the partial-sum slab");
@@ -228,14 +228,30 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.xt2 = epi ? epi->xt2 : nullptr;
   a.x_out = epi ? epi->x_out : nullptr;
   a.x_bits = epi ? epi->x_bits : nullptr;
+  a.pre_x = epi ? epi->pre_x : nullptr;
+  a.pre_w = epi ? epi->pre_w : nullptr;
+  a.pre_xs = epi ? epi->pre_xs : nullptr;
+  a.pre_xt = epi ? epi->pre_xt : nullptr;
+  a.pre_relu = epi ? epi->pre_relu : 0;
+  a.pre_cin = epi ? epi->pre_cin : 0;
+  a.pre_y_out = epi ? epi->pre_y_out : nullptr;
+  const bool pws = pws_selected(d, epi, dtype);
   if (a.xs || a.xb) {
-    MAAI_CHECK_ARG(a.xs && a.xt && emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && d->out_stride == 1 && !a.a2,
+    MAAI_CHECK_ARG(a.xs && a.xt && (emode == MAAI_EPI_STORE || (emode == MAAI_EPI_STATS_ONLY && pws)) && !d->accumulate && !relu_mask &&
+                       d->out_stride == 1 && !a.a2,
                    "conv2d_igemm: the normalised-on-load operand needs xs and xt and a plain dense forward launch");
     const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
     MAAI_CHECK_ARG(!a.xb || pw1, "conv2d_igemm: the two-tensor join on load is for pointwise stride-1 layers");
     MAAI_CHECK_ARG((a.xs2 == nullptr) == (a.xt2 == nullptr) && (a.xb || (!a.xs2 && !a.x_out && !a.x_bits)),
                    "conv2d_igemm: xs2/xt2 come in pairs and, like x_out/x_bits, belong to the two-tensor join");
     MAAI_CHECK_ARG(!a.x_bits || (a.x_out && dtype == MAAI_BF16), "conv2d_igemm: the 1-bit mask of the joined activation is for bf16 x_out");
+  }
+  if (a.pre_x) {
+    const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+    MAAI_CHECK_ARG(a.pre_w && a.xb && a.xs && a.xt && a.x_out && y && dtype == MAAI_BF16 && pw1 && emode == MAAI_EPI_STORE &&
+                       (a.pre_xs == nullptr) == (a.pre_xt == nullptr) && d->OH == d->OHg && d->OW == d->OWg,
+                   "conv2d_igemm: a chained launch is a bf16 pointwise two-tensor join with pre_w and x_out");
+    MAAI_CHECK_ARG(a.pre_cin == 64 && d->Cin == 256, "conv2d_igemm: the chained launch is built for pre_cin 64, Cin 256");
   }
   const bool axf = a.a2 != nullptr;
   if (axf) {
@@ -265,7 +281,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   ConvSel sel;
   sel.dtype = dtype; sel.bm = plan.bm; sel.halo = plan.halo; sel.nstage = 3;
   sel.pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
-  if (pws_selected(d, epi, dtype)) {
+  if (a.pre_x) return maai_conv_chain_launch(a, st);
+  if (pws) {
     if (!relu_mask) return maai_conv_pws_launch(a, st);
     plan.bm = 128;   // the slab rows promised for this shape (a masked launch never carries a join: 128-row tiles)
     sel.bm = 128;
@@ -323,14 +340,11 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
 /* the same for a launch with an epilogue descriptor (the transformed-operand launches use 128-row tiles) */
 extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype) {
   if (!d) return 0;
-  if (epi && (epi->a2 || (epi->mode >= MAAI_EPI_STATS_ONLY && epi->mode <= MAAI_EPI_BWD_APPLY)))
+  if (epi && (epi->a2 || epi->pre_x || (epi->mode >= MAAI_EPI_STATS_ONLY && epi->mode <= MAAI_EPI_BWD_APPLY)))
     return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   const ConvPlan p = conv_plan(d, dtype);
   if (epi && epi->xs && p.bm == 64) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
-  if (pws_selected(d, epi, dtype)) {
-    const int rows = maai_conv_pws_tile_rows(d->Cin);
-    return ((long long)d->N * d->OHg * d->OWg + rows - 1) / rows;
-  }
+  if (pws_selected(d, epi, dtype)) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   return p.nMB;
 }
 

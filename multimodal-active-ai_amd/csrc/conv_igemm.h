@@ -93,6 +93,14 @@ struct ConvArgs {
   const float* xt2;
   void* x_out;
   unsigned char* x_bits;
+  // chained launches (conv_chain.hip): x is not read — it is recomputed as conv(pre_x [M][pre_cin], pre_w [Cin][pre_cin]),
+  // pre_x normalised on load by pre_xs / pre_xt (nullable) — and joined with xb as above; pre_y_out (nullable) keeps it
+  const void* pre_x;
+  const void* pre_w;
+  const float* pre_xs;
+  const float* pre_xt;
+  int pre_relu, pre_cin;
+  void* pre_y_out;
 };
 
 // EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
@@ -864,4 +872,5 @@ struct ConvSel {
 int maai_conv_xf_launch(const ConvArgs& a, const ConvSel& sel, hipStream_t st);
 // conv_pws.hip: the streaming kernel for pointwise layers with Cin <= 256 (A operand in registers, weights streamed)
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st);
-int maai_conv_pws_tile_rows(int cin);
+// conv_chain.hip: conv3 (recomputed) + BatchNorm + residual join + the next block's conv1 in one launch
+int maai_conv_chain_launch(const ConvArgs& a, hipStream_t st);

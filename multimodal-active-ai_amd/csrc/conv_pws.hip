@@ -24,18 +24,17 @@ __device__ __forceinline__ void wait_vm() {
 // one read in step s-2, whose MFMAs every wave has ISSUED (hence whose LDS reads have returned) before it reached the
 // barrier of step s-1 — safe wherever the compiler schedules the MFMAs of step s-1 around the barrier of step s (the
 // K loop is fully unrolled here and hipcc does sink them below it, with their fragment reads still outstanding).
-// EMODE 0: plain store (+ statistics slab); 5: accumulate and/or ReLU mask; 6: 5 + BN-backward sums (DGRAD_REDUCE).
-// TM = 16-row MFMA tiles per wave: 2 (128-row workgroup tile), or 1 (64 rows) for Cin 512, whose K extent fills the registers.
-template <int KC, int BN, int DIST, int XF, int EMODE, int TM = 2>
-__global__ __launch_bounds__(256, KC == 512 ? 2 : (BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4))) void conv_pws_kernel(ConvArgs a) {
+// EMODE 0: plain store (+ statistics slab); 1: statistics slab only (the chained launch of conv_chain.hip recomputes the tensor).
+template <int KC, int BN, int DIST, int XF, int EMODE>
+__global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
   typedef bf16_t T;
-  constexpr int BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
+  constexpr int TM = 2, BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
   constexpr int LDC = BN + 8;              // private C tile row pitch (elements)
   constexpr int CW = 16 * LDC * 2;         // bytes of one wave's 16-row C area
   constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
   constexpr int RPI = 64 / CPR;            // rows one wave-wide 16-byte access covers
   constexpr int NIT = 16 / RPI;            // such accesses per 16-row group
-  constexpr int NST = TM * NIT;            // global stores per wave per column tile
+  constexpr int NST = EMODE == 1 ? 0 : TM * NIT;   // global stores per wave per column tile
   constexpr int NSLOT = DIST + 2;
   constexpr int RING = NSLOT * STAGE;
   typedef Mma<T>::frag frag_t;
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(256, KC == 512 ? 2 : (BN == 128 ? (KC == 256 ? 2 : 
       }
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < (EMODE == 1 ? 0 : TM); ++i) {   // (EMODE 1: statistics only, nothing is stored)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous group's reads of this area are done
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -266,36 +265,34 @@ __global__ __launch_bounds__(256, KC == 512 ? 2 : (BN == 128 ? (KC == 256 ? 2 : 
   finish_stats(nCT - 1);
 }
 
-template <int KC, int BN, int DIST, int XF, int EMODE, int TM = 2>
+template <int KC, int BN, int DIST, int XF, int EMODE>
 static int launch_pws(ConvArgs a, hipStream_t st) {
   constexpr int lds = (DIST + 2) * BN * 64 + 4 * 16 * (BN + 8) * 2 + 32 * BN * 4;
   static_assert(4 * KC * 4 <= 4 * 16 * (BN + 8) * 2, "the coefficient table borrows the C area");
-  a.nMB = (int)((a.M + 64 * TM - 1) / (64 * TM));
+  a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
-  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, TM>), lds, attr_lds);
-  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, TM>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE>), lds, attr_lds);
+  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
 
 template <int KC, int BN>
 static int pws_k(const ConvArgs& a, hipStream_t st) {
-  constexpr int DIST = KC >= 256 ? 3 : 2;
-  if constexpr (KC == 512) {  // the two-tensor join of layer 2 (the only launches this wide that are HBM-bound enough)
-    if (a.xb) return launch_pws<KC, BN, DIST, 2, 0, 1>(a, st);
-    maai_set_error("conv2d_igemm: the 512-channel streaming kernel is built for the join on load");
-    return MAAI_ERR_UNSUPPORTED;
-  } else {
-    if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
-    if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
-    return launch_pws<KC, BN, DIST, 0, 0>(a, st);
+  constexpr int DIST = KC == 256 ? 3 : 2;
+  if (a.emode == MAAI_EPI_STATS_ONLY) {
+    if (a.xb) {
+      maai_set_error("conv2d_igemm: the statistics-only streaming launch takes a plain or normalised-on-load input");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    return a.xs ? launch_pws<KC, BN, DIST, 1, 1>(a, st) : launch_pws<KC, BN, DIST, 0, 1>(a, st);
   }
+  if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
+  if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
+  return launch_pws<KC, BN, DIST, 0, 0>(a, st);
 }
 
-// rows of the output (= of the statistics slab) per workgroup
-int maai_conv_pws_tile_rows(int cin) { return cin == 512 ? 64 : 128; }
-
-// One row tile per workgroup.  Column tile: 64 output channels (4 workgroups per CU; 3 for Cin 256) except for Cin >= 256
+// One 128-row tile per workgroup (the statistics slab's rows).  Column tile: 64 output channels (4 workgroups per CU; 3 for Cin 256) except for Cin >= 256
 // with many output channels, where the MFMA share is large enough for the 128-wide tile's fewer barriers to win
 // (256->1024: 0.64 vs 0.67 ms).  MAAI_PWS_BN = 64 | 128 overrides.
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st) {
@@ -306,7 +303,6 @@ int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st) {
     case 64: return n128 ? pws_k<64, 128>(a, st) : pws_k<64, 64>(a, st);
     case 128: return n128 ? pws_k<128, 128>(a, st) : pws_k<128, 64>(a, st);
     case 256: return n128 ? pws_k<256, 128>(a, st) : pws_k<256, 64>(a, st);
-    case 512: return n128 ? pws_k<512, 128>(a, st) : pws_k<512, 64>(a, st);
     default: break;
   }
   maai_set_error("conv2d_igemm: no streaming pointwise kernel for this channel count");

@@ -28,7 +28,8 @@ class ConvEpilogue(C.Structure):
     """maai_conv_epilogue"""
     _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p), ("mask_bits", c_i), ("sum_increment", c_i),
                 ("a2", c_p), ("ak1", c_p), ("ak2", c_p), ("ak3", c_p), ("a_out", c_p),
-                ("xs", c_p), ("xt", c_p), ("x_relu", c_i), ("xb", c_p), ("xs2", c_p), ("xt2", c_p), ("x_out", c_p), ("x_bits", c_p)]
+                ("xs", c_p), ("xt", c_p), ("x_relu", c_i), ("xb", c_p), ("xs2", c_p), ("xt2", c_p), ("x_out", c_p), ("x_bits", c_p),
+                ("pre_x", c_p), ("pre_w", c_p), ("pre_xs", c_p), ("pre_xt", c_p), ("pre_relu", c_i), ("pre_cin", c_i), ("pre_y_out", c_p)]
 
 
 EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY, EPI_DGRAD_REDUCE = range(6)
@@ -92,7 +93,7 @@ class MaaiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
+ABI_VERSION = 3   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
 
 
 def _autobuild():

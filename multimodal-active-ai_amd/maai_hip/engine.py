@@ -284,6 +284,31 @@ _EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0"}
 # (tests).  MAAI_LAZY_POLICY overrides.
 _LAZY = {"enabled": os.environ.get("MAAI_LAZY", "1") != "0", "join": os.environ.get("MAAI_JOIN", "1") != "0",
          "policy": os.environ.get("MAAI_LAZY_POLICY", "auto")}
+# Chained block boundary (csrc/conv_chain.hip): in a forward that no backward follows, the last convolution of a
+# 64 -> 256 bottleneck runs as a statistics-only launch and the next block's conv1 recomputes it inside the launch that
+# joins it with the shortcut — y3 is neither written nor read (measured at 224^2 x 256 images, per boundary: conv3 1.7 +
+# join 4.1 ms -> statistics 0.73 + chained 3.5 ms).  With a backward pass y3 has to be stored and the chained launch
+# loses (6.3 vs 5.8 ms), so those forwards keep the two launches.  MAAI_CHAIN=0 turns it off.
+_CHAIN = {"enabled": os.environ.get("MAAI_CHAIN", "1") != "0"}
+
+
+def set_chain(enabled):
+    """Chained block boundaries in forwards without a backward pass (default on; MAAI_CHAIN=0).  Everything the chained
+    launch writes — output, joined activation, mask, statistics slab — is bit-identical to the launches it replaces."""
+    _CHAIN["enabled"] = bool(enabled)
+
+
+def _chain_ok(conv, x, dtype):
+    """Can ``conv`` (the last convolution of a block, input ``x``) be recomputed by the next block's chained launch?"""
+    if not (_CHAIN["enabled"] and dtype == torch.bfloat16 and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.in_channels == 64 and conv.out_channels == 256):
+        return False
+    if isinstance(x, K.Lazy) and (x.b is not None or x.pre is not None):
+        return False
+    # the statistics-only launch of a lazy input exists on the streaming kernel only: not when it is switched off or a
+    # ring-kernel tile is forced (the parity tests do both)
+    env = os.environ
+    return env.get("MAAI_CONV_PWS", "1") != "0" and not any(k in env for k in ("MAAI_CONV_BM", "MAAI_CONV_BN", "MAAI_CONV_NSTAGE"))
 
 
 def set_lazy(lazy=None, join=None, policy=None):
@@ -322,11 +347,14 @@ def materialise(x):
     """The tensor a ``kernels.Lazy`` activation stands for (one BatchNorm pass); tensors pass through."""
     if not isinstance(x, K.Lazy):
         return x
+    y = x.y
+    if x.pre is not None:   # a tensor that was never stored: one plain launch of its producer
+        y = K.conv2d(x.pre[0], x.pre[1])
     if x.b is None:
-        return K.bn_act_fwd(x.y, x.scale, x.shift, None, x.relu)
+        return K.bn_act_fwd(y, x.scale, x.shift, None, x.relu)
     if x.scale2 is None:
-        return K.bn_act_fwd(x.y, x.scale, x.shift, x.b, x.relu)
-    return K.bn_act_fwd2(x.y, x.scale, x.shift, x.b, x.scale2, x.shift2, x.relu)
+        return K.bn_act_fwd(y, x.scale, x.shift, x.b, x.relu)
+    return K.bn_act_fwd2(y, x.scale, x.shift, x.b, x.scale2, x.shift2, x.relu)
 
 
 def unit_output(rec):
@@ -464,7 +492,10 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     def conv_x(stats):
         """the convolution of this unit; a two-tensor lazy input is joined on load and handed back through ``side``"""
         if isinstance(x, K.Lazy) and x.b is not None:
-            res = K.conv2d(x, wq, stride, pad, pad_w, stats=stats, join_out=True, join_bits=join_bits)
+            if x.pre is not None:   # the previous block's last convolution is recomputed inside this launch
+                res = K.conv2d_chained(x, wq, stats=stats, join_bits=join_bits)
+            else:
+                res = K.conv2d(x, wq, stride, pad, pad_w, stats=stats, join_out=True, join_bits=join_bits)
             nret = 2 if stats else 1
             if side is None:
                 raise MaaiError("unit_fwd: a joined input needs ``side`` to hand the activation back")
@@ -478,10 +509,12 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         y = conv_x(False)
         mean, invstd, scale, shift, count, world = given.mean, given.invstd, given.scale, given.shift, given.count, given.world
     elif training:
-        if fused:
+        chain = (lazy_out and not keep and not fused and not defer and form == "fwd" and (residual is not None or branch is not None)
+                 and _chain_ok(conv, x, dtype))
+        if fused or chain:
             part = K.conv2d_stats_only(x, wq)
             c = wq.shape[0]
-            count = x.numel() // x.shape[-1]
+            count = x.numel() // x.shape[-1] if not isinstance(x, K.Lazy) else x.y.numel() // x.y.shape[-1]
         else:
             y, part = conv_x(True)
             c = y.shape[-1]
@@ -534,11 +567,12 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             raise MaaiError("unit_fwd: a deferred unit is a plain conv + BN shortcut branch")
         out = None
     elif lazy_out:
-        # no BatchNorm pass here: the consumer convolutions form the activation on load
+        # no BatchNorm pass here: the consumer convolutions form the activation on load (y None: and recompute it)
+        pre = (x, wq) if y is None else None
         if branch is not None:
-            lz = K.Lazy(y, scale, shift, relu, branch[0], branch[1], branch[2])
+            lz = K.Lazy(y, scale, shift, relu, branch[0], branch[1], branch[2], pre=pre)
         else:
-            lz = K.Lazy(y, scale, shift, relu, residual)
+            lz = K.Lazy(y, scale, shift, relu, residual, pre=pre)
         if not keep:
             return lz, None
         r = _Rec()

@@ -115,27 +115,34 @@ class Lazy(object):
     """An activation that exists only as the raw convolution output it is computed from: act(y*scale + shift), or
     the join act((y*scale + shift) + r(b*scale2 + shift2)) of two raw tensors (b added as is when scale2 is None).
     Consumers (conv2d / conv2d_wgrad with ``xf=``) form it on load (maai_conv_epilogue.xs ...)."""
-    __slots__ = ("y", "scale", "shift", "relu", "b", "scale2", "shift2")
+    __slots__ = ("y", "scale", "shift", "relu", "b", "scale2", "shift2", "pre")
 
-    def __init__(self, y, scale, shift, relu=True, b=None, scale2=None, shift2=None):
+    def __init__(self, y, scale, shift, relu=True, b=None, scale2=None, shift2=None, pre=None):
         self.y, self.scale, self.shift, self.relu, self.b, self.scale2, self.shift2 = y, scale, shift, relu, b, scale2, shift2
+        # pre = (x, w): ``y`` does not exist — it is the pointwise convolution conv(x, w) (x a tensor or a single-tensor
+        # Lazy), whose statistics gave (scale, shift); a chained launch recomputes it (conv2d with join_out)
+        self.pre = pre
+        if pre is not None and (y is not None or b is None):
+            raise MaaiError("Lazy: a recomputed tensor has no y and is one side of a join")
 
     @property
     def shape(self):
-        return self.y.shape
+        if self.y is not None:
+            return self.y.shape
+        return tuple(self.b.shape)
 
     @property
     def dtype(self):
-        return self.y.dtype
+        return self.b.dtype if self.y is None else self.y.dtype
 
 
 def _xf_epilogue(xf, join_out=None, join_bits=None):
     _gpu(xf.y, xf.scale, xf.shift, xf.b, xf.scale2, xf.shift2, join_out, join_bits)
-    c = xf.y.shape[-1]
+    c = xf.shape[-1]
     for t in (xf.scale, xf.shift, xf.scale2, xf.shift2):
         if t is not None and (t.dtype != torch.float32 or t.numel() != c):
             raise MaaiError("normalise-on-load: per-channel coefficients must be fp32 [Cin]")
-    if xf.b is not None and (xf.b.shape != xf.y.shape or xf.b.dtype != xf.y.dtype):
+    if xf.b is not None and xf.y is not None and (xf.b.shape != xf.y.shape or xf.b.dtype != xf.y.dtype):
         raise MaaiError("normalise-on-load: the second tensor must match the first")
     if (xf.scale2 is None) != (xf.shift2 is None) or (xf.b is None and (xf.scale2 is not None or join_out is not None)):
         raise MaaiError("normalise-on-load: scale2/shift2/out belong to the two-tensor join")
@@ -185,7 +192,57 @@ def conv2d(x, w, stride=1, pad_h=0, pad_w=0, stats=False, out=None, grid_hw=None
     return (out, part) if stats else out
 
 
+def _conv2d_chained(xf, w, stats, join_bits, keep_y):
+    """conv(join(conv(pre_x, pre_w) normalised by (scale, shift), b), w): one launch (csrc/conv_chain.hip).  Returns
+    (out [, stats], joined [, bits] [, y]) — y, the recomputed raw tensor, only when ``keep_y``."""
+    px, pw = xf.pre
+    plazy = px if isinstance(px, Lazy) else None
+    pt = plazy.y if plazy is not None else px
+    if plazy is not None and (plazy.b is not None or plazy.pre is not None):
+        raise MaaiError("conv2d: the producer of a chained launch takes a tensor or a single-tensor Lazy")
+    b = xf.b
+    _gpu(pt, pw, b, w)
+    if not (pt.dtype == pw.dtype == b.dtype == w.dtype == torch.bfloat16):
+        raise MaaiError("conv2d: chained launches are bf16")
+    if tuple(pw.shape[1:3]) != (1, 1) or pw.shape[0] != b.shape[-1] or pw.shape[3] != pt.shape[-1] or pt.shape[:3] != b.shape[:3]:
+        raise MaaiError("conv2d: the chained producer must be a pointwise convolution onto the join's channels")
+    d = make_desc(b, w, 1, 0, 0)
+    out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=b.dtype, device=b.device)
+    jo = torch.empty_like(b)
+    jb = torch.empty((b.numel() // 8,), dtype=torch.uint8, device=b.device) if join_bits else None
+    yk = torch.empty_like(b) if keep_y else None
+    epi = _xf_epilogue(xf, jo, jb)
+    epi.pre_x, epi.pre_w, epi.pre_cin = pt.data_ptr(), pw.data_ptr(), pt.shape[-1]
+    if plazy is not None:
+        _gpu(plazy.scale, plazy.shift)
+        epi.pre_xs, epi.pre_xt, epi.pre_relu = plazy.scale.data_ptr(), plazy.shift.data_ptr(), 1 if plazy.relu else 0
+    if yk is not None:
+        epi.pre_y_out = yk.data_ptr()
+    part = None
+    if stats:
+        rows = lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), BF16)
+        part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=b.device)
+    m = d.N * d.OHg * d.OWg
+    nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[chain] M%d Cin%d Cout%d k1x1 s1 os1 acc0" % (m, d.Cin, d.Cout)
+    nbytes = 2 * (pt.numel() + b.numel() * (2 + (1 if keep_y else 0)) + pw.numel() + w.numel() + m * d.Cout) + (0 if jb is None else jb.numel())
+    flops = 2.0 * m * (d.Cout * d.Cin + d.Cin * pt.shape[-1])
+    # SURVEY §8(d) bytes of what this launch replaces: this convolution's input once + output once (the recomputation
+    # of the producer stands in for the read of its output)
+    with _timed(nm, flops, nbytes, 2 * (b.numel() + m * d.Cout)):
+        check(lib().maai_conv2d_igemm_fused(C.byref(d), None, _p(w), _p(out), _p(part), None, C.byref(epi), BF16, _stream()),
+              "maai_conv2d_igemm_fused")
+    ret = (out, part) if stats else (out,)
+    ret = ret + (jo,)
+    if join_bits:
+        ret = ret + (jb,)
+    if keep_y:
+        ret = ret + (yk,)
+    return ret
+
+
 def _conv2d_lazy(xf, w, stride, pad_h, pad_w, stats, join_out, join_bits):
+    if xf.pre is not None:
+        raise MaaiError("conv2d: a recomputed input goes through conv2d_chained")
     x = xf.y
     _gpu(x, w)
     if x.dtype != w.dtype:
@@ -286,11 +343,35 @@ def _stats_slab(x, w, stride, pad_h, pad_w, mode=EPI_STATS_ONLY):
 
 
 def conv2d_stats_only(x, w, stride=1, pad_h=0, pad_w=0):
-    """BatchNorm partial statistics of conv(x, w) without storing the convolution (pass 1 of the fused unit)."""
+    """BatchNorm partial statistics of conv(x, w) without storing the convolution (pass 1 of the fused unit; the
+    producer side of a chained launch).  ``x`` may be a single-tensor ``Lazy`` where the streaming kernel takes the shape."""
+    if isinstance(x, Lazy):
+        if x.b is not None or x.pre is not None:
+            raise MaaiError("conv2d_stats_only: a single-tensor Lazy")
+        xt = x.y
+        _gpu(xt, w)
+        d = make_desc(xt, w, stride, pad_h, pad_w)
+        epi = _xf_epilogue(x)
+        epi.mode = EPI_STATS_ONLY
+        rows = lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(xt))
+        part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=xt.device)
+        m = d.N * d.OHg * d.OWg
+        nm = "conv_stats_only" if not DETAIL[0] else "conv_stats_only[xf1] M%d Cin%d Cout%d" % (m, d.Cin, d.Cout)
+        with _timed(nm, 2.0 * m * d.Cout * d.Cin, xt.element_size() * (xt.numel() + w.numel()), 0.0):
+            check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(xt), _p(w), None, _p(part), None, C.byref(epi), _dt(xt), _stream()),
+                  "maai_conv2d_igemm_fused")
+        return part
     _gpu(x, w)
     part, _ = _stats_slab(x, w, stride, pad_h, pad_w)
     _conv_fused(x, w, stride, pad_h, pad_w, EPI_STATS_ONLY, None, part)
     return part
+
+
+def conv2d_chained(xf, w, stats=False, join_bits=False, keep_y=False):
+    """See ``_conv2d_chained``; ``xf`` is a ``Lazy`` with ``pre`` set."""
+    if not isinstance(xf, Lazy) or xf.pre is None:
+        raise MaaiError("conv2d_chained: a Lazy carrying its producer")
+    return _conv2d_chained(xf, w, stats, join_bits, keep_y)
 
 
 def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=0, pad_w=0):

@@ -85,12 +85,52 @@ def join_case(hw, cin, cout, proj):
     return same
 
 
+def chain_case(hw, cout, proj):
+    """block boundary of layer 1: conv3 (64->256, lazy input) + join + next conv1, unchained vs chained"""
+    n = B
+    a2 = torch.randn(n, hw, hw, 64, device="cuda").bfloat16()
+    w3 = (torch.randn(256, 1, 1, 64, device="cuda") / 8).bfloat16()
+    w1 = (torch.randn(cout, 1, 1, 256, device="cuda") / 16).bfloat16()
+    sc = torch.randn(n, hw, hw, 256, device="cuda").bfloat16()
+    ps, pt = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.3
+    s3, t3 = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda") * 0.3
+    src = K.Lazy(a2, ps, pt, True)
+    extra = (sc, s3 + 0.1, t3 - 0.1) if proj else (sc.clamp_min(0),)
+    os.environ.update(ARMS["ring"])
+    os.environ["MAAI_CONV_PWS"] = "1"
+    y3, _ = K.conv2d(src, w3, stats=True)
+
+    def ev(fn, rounds=5):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
+    t_conv3 = ev(lambda: K.conv2d(src, w3, stats=True))
+    t_join = ev(lambda: K.conv2d(K.Lazy(y3, s3, t3, True, *extra), w1, stats=True, join_out=True, join_bits=True))
+    t_stats = ev(lambda: K.conv2d_stats_only(src, w3))
+    lz = K.Lazy(None, s3, t3, True, *extra, pre=(src, w3))
+    t_ch0 = ev(lambda: K.conv2d_chained(lz, w1, stats=True, join_bits=False, keep_y=False))
+    t_ch1 = ev(lambda: K.conv2d_chained(lz, w1, stats=True, join_bits=True, keep_y=True))
+    print("chain 64->256->%3d @%3d %s: conv3 %.3f + join %.3f = %.3f ms | stats-only %.3f + chain %.3f = %.3f (no backward) ; + chain(keep y, bits) %.3f = %.3f" %
+          (cout, hw, "proj" if proj else "iden", t_conv3, t_join, t_conv3 + t_join, t_stats, t_ch0, t_stats + t_ch0, t_ch1, t_stats + t_ch1), flush=True)
+
+
 if __name__ == "__main__":
     print("B = %d" % B)
     ok = True
+    if len(sys.argv) > 2 and sys.argv[2] == "chain":
+        for hw, cout, proj in ((224, 64, False), (224, 128, False), (224, 64, True)):
+            chain_case(hw, cout, proj)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "join":
-        for hw, cin, cout, proj in ((112, 512, 128, False), (112, 512, 256, False), (112, 512, 128, True), (224, 256, 64, False), (224, 256, 128, False),
-                                    (56, 512, 256, False)):
+        for hw, cin, cout, proj in ((224, 256, 64, False), (224, 256, 128, False), (224, 256, 64, True), (112, 256, 128, False)):
             ok &= join_case(hw, cin, cout, proj)
         print("all identical" if ok else "MISMATCH")
         sys.exit(0 if ok else 1)

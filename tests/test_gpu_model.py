@@ -488,9 +488,10 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
     res = {}
     try:
         for tag, (lazy, join, rec) in (("plain", (False, False, False)), ("lazy", (True, False, False)), ("join", (True, True, False)),
-                                       ("join+recompute", (True, True, True))):
+                                       ("join+recompute", (True, True, True)), ("join+chain", (True, True, False))):
             engine.set_lazy(lazy, join, "all")
             engine.set_recompute(rec)
+            engine.set_chain(tag == "join+chain")
             m = _build(mods, arch, cm, head_in, shape[0], shape[2:], 0.5)
             m.train()
             with torch.no_grad():
@@ -510,9 +511,10 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
     finally:
         engine.set_lazy(True, True, "auto")
         engine.set_recompute(False)
-    for tag in ("lazy", "join", "join+recompute"):
+        engine.set_chain(True)
+    for tag in ("lazy", "join", "join+recompute", "join+chain"):
         assert torch.equal(res[tag][0], res["plain"][0]), tag
-        assert torch.equal(res[tag][4], res["plain"][4]), tag
+        assert torch.equal(res[tag][4], res["plain"][4]), tag   # (join+chain: conv3 recomputed inside the next block's conv1)
         for n, b in res["plain"][3].items():
             assert torch.equal(res[tag][3][n], b), (tag, n)
         assert res[tag][1].keys() == res["plain"][1].keys() and len(res["plain"][1]) > 50

@@ -101,8 +101,7 @@ def test_shape_rule_and_knob_precedence(K):
 
 @pytest.mark.parametrize("bn", ["64", "128"])
 @pytest.mark.parametrize("shortcut", ["identity", "projection"])
-@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (3, 15, 15, 256, 64), (1, 9, 11, 128, 128), (2, 12, 12, 256, 1024),
-                                  (2, 12, 12, 512, 128), (1, 9, 11, 512, 256), (3, 8, 8, 512, 64)],   # 512: 64-row tiles
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 256), (3, 15, 15, 256, 64), (1, 9, 11, 128, 128), (2, 12, 12, 256, 1024)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_streaming_join_on_load_matches_ring_kernel(K, case, shortcut, bn):
     """the residual join relu(bn3(y3) + shortcut) formed on load (resnet.py:126-133): output, joined tensor, 1-bit mask"""
@@ -125,7 +124,47 @@ def test_streaming_join_on_load_matches_ring_kernel(K, case, shortcut, bn):
     (y0, st0, j0, b0), (y1, st1, j1, b1) = res
     assert torch.equal(y0, y1) and torch.equal(j0, j1) and torch.equal(b0, b1)
     m = n * h * w_
-    rows = 64 if cin == 512 else 128
-    assert st1.shape == ((m + rows - 1) // rows, 2, cout)
+    assert st1.shape == ((m + 127) // 128, 2, cout)
     t0, t1 = st0.double().sum(0), st1.double().sum(0)
     assert bool(((t0 - t1).abs() <= 2e-6 * (st0.double().abs().sum(0) + 1.0)).all())
+
+
+@pytest.mark.parametrize("keep", [False, True], ids=["nokeep", "keep-y"])
+@pytest.mark.parametrize("shortcut", ["identity", "projection"])
+@pytest.mark.parametrize("pre_lazy", [False, True], ids=["tensor", "lazy"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64), (3, 15, 15, 128), (1, 9, 11, 64), (1, 56, 56, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_chained_block_boundary_matches_unchained(K, case, pre_lazy, shortcut, keep):
+    """conv3 -> bn3 -> (+ shortcut) -> relu -> next conv1 (resnet.py:118-133, :101) in ONE launch with conv3 recomputed
+    (csrc/conv_chain.hip) against the sequence it replaces: conv3 stored, then the join-on-load conv1.  Bit-identical
+    output, joined activation, mask and (when kept) recomputed tensor; the statistics-only launch gives conv3's slab."""
+    n, h, w_, cout = case
+    g = torch.Generator().manual_seed(hash(case) % 10007 + 3)
+    a2 = torch.randn(n, h, w_, 64, generator=g).cuda().bfloat16()
+    w3 = (torch.randn(256, 1, 1, 64, generator=g) / 8).cuda().bfloat16()
+    w1 = (torch.randn(cout, 1, 1, 256, generator=g) / 16).cuda().bfloat16()
+    sc = torch.randn(n, h, w_, 256, generator=g).cuda().bfloat16()
+    s3, t3 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.5).cuda()
+    if pre_lazy:
+        ps = ((torch.rand(64, generator=g) + 0.5) * torch.where(torch.rand(64, generator=g) < 0.2, -1.0, 1.0)).cuda()
+        pt = (torch.randn(64, generator=g) * 0.5).cuda()
+        src = K.Lazy(a2, ps, pt, True)
+    else:
+        src = a2
+    if shortcut == "projection":
+        s2, t2 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.5).cuda()
+        extra = (sc, s2, t2)
+    else:
+        extra = (sc.clamp_min(0),)
+    with env(MAAI_CONV_PWS="2", MAAI_PWS_BN="64"):   # (the reference join on the streaming kernel: same slab arithmetic)
+        y3, st3 = K.conv2d(src, w3, stats=True)
+        y1, st1, jo, jb = K.conv2d(K.Lazy(y3, s3, t3, True, *extra), w1, stats=True, join_out=True, join_bits=True)
+    st3b = K.conv2d_stats_only(src, w3)
+    got = K.conv2d_chained(K.Lazy(None, s3, t3, True, *extra, pre=(src, w3)), w1, stats=True, join_bits=True, keep_y=keep)
+    torch.cuda.synchronize()
+    assert torch.equal(st3, st3b)
+    assert torch.equal(got[0], y1) and torch.equal(got[2], jo) and torch.equal(got[3], jb)
+    assert torch.equal(got[1], st1)
+    if keep:
+        assert torch.equal(got[4], y3)
+    y1r, st1r, jor, jbr = K.conv2d(K.Lazy(y3, s3, t3, True, *extra), w1, stats=True, join_out=True, join_bits=True)   # default dispatch
+    assert torch.equal(got[0], y1r) and torch.equal(got[2], jor) and torch.equal(got[3], jbr)
