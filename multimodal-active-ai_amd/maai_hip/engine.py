@@ -262,7 +262,10 @@ def _check_conv(conv):
 
 
 _DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
-_EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0"}
+# Inference with frozen statistics: conv + BN (+ shortcut) + ReLU in ONE launch per unit (MAAI_EPI_BN_ACT) where the tensors
+# are small enough for launch count to matter; on large ones the lazy / streaming / chained path of the training forward
+# (minus its statistics) is faster (ResNet-50, 224^2 x 256: 79.6 vs 67.8 ms).  max_rows: output pixels up to which a unit fuses.
+_EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0", "max_rows": int(os.environ.get("MAAI_EVAL_FUSE_MAX_ROWS", "65536"))}
 # Normalise-on-load (kernels.Lazy): a unit whose only consumers are convolutions of this library does not run its
 # BatchNorm/ReLU pass; it hands on its RAW convolution output with (scale, shift) and the consumers (forward
 # convolution, weight gradient) apply the transform to the operand they stage in LDS.  "lazy": inside a block
@@ -481,8 +484,9 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
     fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
+    rows_out = (x.shape[0] * ((x.shape[1] + 2 * pad - kh) // stride + 1) * ((x.shape[2] + 2 * pad_w - kw) // stride + 1))
     eval_fused = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
-                  and wq.shape[0] % 64 == 0)
+                  and wq.shape[0] % 64 == 0 and rows_out <= _EVAL_FUSE["max_rows"])
     if isinstance(x, K.Lazy) and (fused or eval_fused or form != "fwd" or not _lazy_input_ok(x, conv, dtype)):
         x = materialise(x)
         if side is not None:
@@ -504,13 +508,15 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             return (res[0], res[1]) if stats else res[0]
         return K.conv2d(x, wq, stride, pad, pad_w, stats=stats)
     y = None
+    # chained block boundary: this convolution is not run here (training: only its statistics are taken) — the next block's
+    # first convolution recomputes it inside the launch that joins it with the shortcut
+    chain = (lazy_out and not keep and not fused and not eval_fused and not defer and given is None and form == "fwd"
+             and (residual is not None or branch is not None) and _chain_ok(conv, x, dtype))
     if given is not None:
         training = given.training
         y = conv_x(False)
         mean, invstd, scale, shift, count, world = given.mean, given.invstd, given.scale, given.shift, given.count, given.world
     elif training:
-        chain = (lazy_out and not keep and not fused and not defer and form == "fwd" and (residual is not None or branch is not None)
-                 and _chain_ok(conv, x, dtype))
         if fused or chain:
             part = K.conv2d_stats_only(x, wq)
             c = wq.shape[0]
@@ -540,10 +546,10 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             # inference with frozen statistics: normalise (+ shortcut) + activate in the convolution's own epilogue,
             # one launch per unit and no raw conv output in HBM (MAAI_EPI_BN_ACT on any kernel size)
             return K.conv2d_bn_act(x, wq, scale, shift, residual, relu, stride, pad, pad_w), None
-        if not fused:
+        if not fused and not chain:
             y = conv_x(False)
         mean = invstd = None
-        count, world = x.numel() // x.shape[-1] if fused else y.numel() // y.shape[-1], 1
+        count, world = (x.numel() // x.shape[-1] if fused else (y.numel() // y.shape[-1] if y is not None else 0)), 1
     if isinstance(branch, list):
         branch = branch[0]   # the shortcut branch, finalised by the same exchange (_drive_pair)
     xb = side["joined"] if (side is not None and isinstance(x, K.Lazy) and x.b is not None) else x  # what the backward reads

@@ -14,8 +14,8 @@ f.train()
 with torch.no_grad():
     engine.backbone_fwd(f, x, dtype, keep=False)
 f.eval()
-for flag in (True, False, True, False):
-    engine._EVAL_FUSE["enabled"] = flag
+for flag in (1 << 40, 0, 250000, 1000000, 1 << 40, 0):   # rows up to which a unit uses the fused epilogue
+    engine._EVAL_FUSE["max_rows"] = flag
     with torch.no_grad():
         for _ in range(2):
             engine.backbone_fwd(f, x, dtype, keep=False)
@@ -26,4 +26,4 @@ for flag in (True, False, True, False):
             engine.backbone_fwd(f, x, dtype, keep=False)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("eval forward, fused=%s: %.1f ms  %.0f images/s" % (flag, dt * 1e3, B / dt), flush=True)
+    print("eval forward, fused epilogues up to %d rows: %.1f ms  %.0f images/s" % (flag, dt * 1e3, B / dt), flush=True)
