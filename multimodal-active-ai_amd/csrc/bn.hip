@@ -25,6 +25,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   const float* p = partial + col;
   long long r = r0 + slot;
+  for (; r + 7 * nslot < r1; r += 8 * nslot) {  // eight rows (128 bytes per lane) in flight: the slabs of the full-resolution
+    float4 v[8];                                //  stages are hundreds of MB, streamed once (non-temporal)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint4 u = ld16_nt(p + (r + k * nslot) * C2);
+      v[k] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+    }
+    s0 += (((double)v[0].x + (double)v[1].x) + ((double)v[2].x + (double)v[3].x)) + (((double)v[4].x + (double)v[5].x) + ((double)v[6].x + (double)v[7].x));
+    s1 += (((double)v[0].y + (double)v[1].y) + ((double)v[2].y + (double)v[3].y)) + (((double)v[4].y + (double)v[5].y) + ((double)v[6].y + (double)v[7].y));
+    s2 += (((double)v[0].z + (double)v[1].z) + ((double)v[2].z + (double)v[3].z)) + (((double)v[4].z + (double)v[5].z) + ((double)v[6].z + (double)v[7].z));
+    s3 += (((double)v[0].w + (double)v[1].w) + ((double)v[2].w + (double)v[3].w)) + (((double)v[4].w + (double)v[5].w) + ((double)v[6].w + (double)v[7].w));
+  }
   for (; r + 3 * nslot < r1; r += 4 * nslot) {  // four rows in flight
     const float4 a = *reinterpret_cast<const float4*>(p + r * C2);
     const float4 b = *reinterpret_cast<const float4*>(p + (r + nslot) * C2);
@@ -89,7 +101,7 @@ extern "C" int maai_reduce_partials(const float* partial, long long rows, int C2
     if (L > 64) L = 64;
     const int gx = c4 / L, nslot = 256 / L;
     long long slices = (rows + 8LL * nslot - 1) / (8LL * nslot);  // >= 8 rows per row slot
-    const long long cap = 1024 / gx > 0 ? 1024 / gx : 1;
+    const long long cap = 2048 / gx > 0 ? 2048 / gx : 1;
     if (slices > cap) slices = cap;
     if (slices < 1) slices = 1;
     const long long rpb = (rows + slices - 1) / slices;
