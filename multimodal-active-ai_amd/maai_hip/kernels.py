@@ -356,7 +356,7 @@ def conv2d_stats_only(x, w, stride=1, pad_h=0, pad_w=0):
         rows = lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(xt))
         part = torch.empty((rows, 2, d.Cout), dtype=torch.float32, device=xt.device)
         m = d.N * d.OHg * d.OWg
-        nm = "conv_stats_only" if not DETAIL[0] else "conv_stats_only[xf1] M%d Cin%d Cout%d" % (m, d.Cin, d.Cout)
+        nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[stats-only xf1] M%d Cin%d Cout%d k1x1" % (m, d.Cin, d.Cout)
         with _timed(nm, 2.0 * m * d.Cout * d.Cin, xt.element_size() * (xt.numel() + w.numel()), 0.0):
             check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(xt), _p(w), None, _p(part), None, C.byref(epi), _dt(xt), _stream()),
                   "maai_conv2d_igemm_fused")
