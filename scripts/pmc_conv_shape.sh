@@ -21,7 +21,7 @@ acc = collections.defaultdict(lambda: [0, 0.0])
 dur = []
 for f in glob.glob(os.path.join(out, "p*", "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_igemm" not in r["Kernel_Name"]:
+        if not any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_pws", "conv_chain")):
             continue
         a = acc[r["Counter_Name"]]
         a[0] += 1
