@@ -758,8 +758,24 @@ def _unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums=None):
     return k1, k2, k3
 
 
+# The backward of a 64 -> 256 bottleneck's last unit in ONE launch (csrc/conv_bwd3.hip): BatchNorm-backward apply, data
+# gradient (with the mask and the backward sums of the unit below) and weight gradient share one read of the incoming
+# gradient and of y3; dz3 is never written.  Measured at 224^2 x 256 images: apply-on-load data gradient 4.0-5.7 ms +
+# weight gradient 1.35 ms -> 3.75 ms.  MAAI_BWD3=0 turns it off.
+_BWD3 = {"enabled": os.environ.get("MAAI_BWD3", "1") != "0"}
+
+
+def _bwd3_applies(rec, dout, below, need_dx, dx_out, accumulate, relu_mask, dy):
+    w = rec.conv.weight
+    return (_BWD3["enabled"] and dy is None and need_dx and dx_out is None and not accumulate and relu_mask is None
+            and dout.dtype == torch.bfloat16 and tuple(w.shape) == (256, 64, 1, 1) and rec.stride == 1 and rec.pad == 0
+            and w.requires_grad and not rec.fused and rec.y is not None and rec.form == "fwd"
+            and below is not None and below.relu and not below.has_res and below.y is not None and not below.fused
+            and below.scale is not None and below.shift is not None and _DGRAD_REDUCE["enabled"] and not _SIDE["enabled"])
+
+
 def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=False, relu_mask=None, below=None,
-             presums=None, dy=None, sum_increment=False):
+             presums=None, dy=None, sum_increment=False, coeffs=None):
     """Backward of unit_fwd.  CONVENTION: ``dout`` is already multiplied by the ReLU mask of this unit's
     output (the kernel that produced it folded ``* (out > 0)`` into its epilogue), so nothing here reads the
     forward output.  ``relu_mask`` = this unit's post-ReLU input, to pre-mask the returned dx the same way;
@@ -767,6 +783,14 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
     from the same epilogue).  ``presums`` = this unit's own sums if the producer of ``dout`` already reduced them;
     ``dy`` = the gradient wrt the raw conv output if the caller already ran the BatchNorm backward.
     Returns (dx or None, sums for ``below`` or None); parameter gradients go to ``grads``."""
+    if _bwd3_applies(rec, dout, below, need_dx, dx_out, accumulate, relu_mask, dy):
+        # (``coeffs``: the caller already has this unit's BatchNorm-backward coefficients — a projection-shortcut block
+        #  finalises both of its BatchNorms in one exchange)
+        k1, k2, k3 = coeffs if coeffs is not None else unit_bwd_coeffs(rec, dout, grads, dtype, presums)
+        dx, slab, dw = K.conv_bwd3(dout, rec.y, below.y, w_dgrad(rec.conv.weight, dtype, [0], [0]), k1, k2, k3,
+                                   _reduce_mean(below), below.scale, below.shift)
+        grads[id(rec.conv.weight)] = _grad_to_reference(rec, dw)
+        return dx, K.reduce_partials(slab)
     fused_apply = dy is None and axf_applies(rec, dout, below, need_dx) and not any(
         len(c[1]) == 0 for c in dgrad_classes(rec.k, rec.stride, rec.pad))
     if fused_apply:
@@ -954,9 +978,15 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
     if rd is not None and _DUAL_BN["enabled"] and not r3.fused and not rd.fused:
         # both branches receive the same gradient: one pass reads it once and writes both dy
         k3, kd = _drive_pair(_unit_bwd_coeffs_gen(r3, dout, grads, dtype, presums), _unit_bwd_coeffs_gen(rd, dout, grads, dtype))
-        dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
-        d, s = unit_bwd(r3, None, grads, dtype, below=r2 if r2 is not None else r1, dy=dy3)
-        del dy3
+        below3 = r2 if r2 is not None else r1
+        if _bwd3_applies(r3, dout, below3, True, None, False, None, None):
+            # the main branch's apply happens inside its fused backward launch: only the shortcut's is a pass
+            dyd, _ = K.bn_act_bwd_apply(dout, None, rd.y, kd[0], kd[1], kd[2], False, True, False)
+            d, s = unit_bwd(r3, dout, grads, dtype, below=below3, coeffs=k3)
+        else:
+            dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
+            d, s = unit_bwd(r3, None, grads, dtype, below=below3, dy=dy3)
+            del dy3
     else:
         d, s = unit_bwd(r3, dout, grads, dtype, below=r2 if r2 is not None else r1, presums=presums)
     if r2 is not None:

@@ -122,9 +122,48 @@ def chain_case(hw, cout, proj):
           (cout, hw, "proj" if proj else "iden", t_conv3, t_join, t_conv3 + t_join, t_stats, t_ch0, t_stats + t_ch0, t_ch1, t_stats + t_ch1), flush=True)
 
 
+def bwd3_case(hw):
+    """conv3 + bn3 backward of a 64 -> 256 bottleneck: apply-on-load data gradient + weight gradient vs the fused launch"""
+    n = B
+    g = torch.randn(n, hw, hw, 256, device="cuda").bfloat16()
+    y3 = torch.randn(n, hw, hw, 256, device="cuda").bfloat16()
+    y2 = torch.randn(n, hw, hw, 64, device="cuda").bfloat16()
+    wd = (torch.randn(64, 1, 1, 256, device="cuda") / 16).bfloat16()
+    k1, k2, k3 = torch.rand(256, device="cuda") + 0.5, torch.randn(256, device="cuda") * 0.1, torch.randn(256, device="cuda") * 0.1
+    mean2, s2, t2 = torch.zeros(64, device="cuda"), torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.3
+    m = n * hw * hw
+    dx = torch.empty_like(y2)
+    part = torch.zeros((m + 127) // 128, 2, 64, device="cuda")
+    dz = torch.empty_like(g)
+    lz = K.Lazy(y2, s2, t2, True)
+
+    def ev(fn, rounds=5):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
+    t_d = ev(lambda: K.conv2d_store_reduce(g, wd, 1, 0, 0, dx, part, y2, mean2, s2, t2, None, axf=(y3, k1, k2, k3, dz)))
+    t_w = ev(lambda: K.conv2d_wgrad(lz, dz, 1, 1, 1, 0, 0))
+    t_f = ev(lambda: K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2))
+    by = 2.0 * m * (256 * 2 + 64 * 2)
+    print("bwd3 @%3d: apply-on-load data gradient %.3f + weight gradient %.3f = %.3f ms | fused %.3f ms (%4.0f GB/s)" %
+          (hw, t_d, t_w, t_d + t_w, t_f, by / t_f / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     print("B = %d" % B)
     ok = True
+    if len(sys.argv) > 2 and sys.argv[2] == "bwd3":
+        bwd3_case(224)
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "chain":
         for hw, cout, proj in ((224, 64, False), (224, 128, False), (224, 64, True)):
             chain_case(hw, cout, proj)

@@ -168,3 +168,38 @@ def test_chained_block_boundary_matches_unchained(K, case, pre_lazy, shortcut, k
         assert torch.equal(got[4], y3)
     y1r, st1r, jor, jbr = K.conv2d(K.Lazy(y3, s3, t3, True, *extra), w1, stats=True, join_out=True, join_bits=True)   # default dispatch
     assert torch.equal(got[0], y1r) and torch.equal(got[2], jor) and torch.equal(got[3], jbr)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16), (3, 15, 15), (1, 9, 11), (1, 56, 56), (4, 30, 30)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_conv3_backward_matches_the_two_launches(K, case):
+    """conv3 + bn3 backward of a 64 -> 256 bottleneck in one persistent launch (csrc/conv_bwd3.hip: BatchNorm-backward
+    apply, data gradient with bn2's mask and sums, weight gradient; dz3 never written) against the sequence it replaces —
+    the apply-on-load data gradient that keeps dz3, then the weight gradient on the lazy input (resnet.py:118-119 backward)."""
+    n, h, w_ = case
+    g_ = torch.Generator().manual_seed(hash(case) % 10007 + 11)
+    g = torch.randn(n, h, w_, 256, generator=g_).cuda().bfloat16()
+    y3 = torch.randn(n, h, w_, 256, generator=g_).cuda().bfloat16()
+    y2 = torch.randn(n, h, w_, 64, generator=g_).cuda().bfloat16()
+    wd = (torch.randn(64, 1, 1, 256, generator=g_) / 16).cuda().bfloat16()
+    k1, k2, k3 = (torch.rand(256, generator=g_) + 0.5).cuda(), (torch.randn(256, generator=g_) * 0.1).cuda(), (torch.randn(256, generator=g_) * 0.1).cuda()
+    mean2 = (torch.randn(64, generator=g_) * 0.1).cuda()
+    s2, t2 = (torch.rand(64, generator=g_) + 0.5).cuda(), (torch.randn(64, generator=g_) * 0.3).cuda()
+    m = n * h * w_
+    dx0 = torch.empty_like(y2)
+    part0 = torch.zeros((m + 127) // 128, 2, 64, device="cuda")
+    dz = torch.empty_like(g)
+    K.conv2d_store_reduce(g, wd, 1, 0, 0, dx0, part0, y2, mean2, s2, t2, None, axf=(y3, k1, k2, k3, dz))
+    dw0 = K.conv2d_wgrad(K.Lazy(y2, s2, t2, True), dz, 1, 1, 1, 0, 0)
+    dx1, part1, dw1 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2)
+    dx2, part2, dw2 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and torch.equal(dx1, dx2)
+    t0, t1 = part0.double().sum(0), part1.double().sum(0)
+    tol = 4e-6 * (part0.double().abs().sum(0) + 1.0) + 1e-5 * float(t0.abs().max())
+    assert bool(((t0 - t1).abs() <= tol).all()), float(((t0 - t1).abs() / tol).max())
+    assert dw1.shape == dw0.shape == (256, 1, 1, 64)
+    scale = float(dw0.abs().max())
+    assert float((dw1 - dw0).abs().max()) <= 2e-5 * scale + 1e-6 * m ** 0.5, float((dw1 - dw0).abs().max() / scale)
+    a2 = K.bn_act_fwd(y2, s2, t2, None, True)
+    ref = torch.einsum("mc,mk->ck", dz.reshape(m, 256).double(), a2.reshape(m, 64).double())
+    assert float((dw1.reshape(256, 64).double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6 * m ** 0.5
