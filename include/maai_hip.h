@@ -158,14 +158,16 @@ long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const maai_conv_
 
 /* Backward of a 64 -> 256 bottleneck's last unit in one launch (bf16; resnet.py:118-119, autograd of conv3 + bn3):
  *   dz = k1*g - k2 - k3*y3 (BatchNorm-backward apply; g, y3: [M][256]),
- *   dx[M][64] = (dz . W3) masked by y2*s2 + t2 > 0 (the ReLU of conv3's input a2 = relu(bn2(y2)), y2: [M][64]),
+ *   dx[M][64] = (dz . W3 (+ dx's previous content when `accumulate`)) masked by y2*s2 + t2 > 0 (the ReLU of conv3's input
+ *              a2 = relu(bn2(y2)), y2: [M][64]),
  *   slab[rows][2][64]: per-workgroup sums of dx and dx*(y2 - mean2) (bn2's backward sums; rows = maai_conv_bwd3_rows(M)),
  *   dw[256][64] (fp32, zeroed by the caller) += dz^T . a2.
  * wd: conv3's weights as [64][1][1][256] (data-gradient form).  dz is never written to memory.  dx and the sums follow
  * maai_conv2d_igemm_fused's DGRAD_REDUCE epilogue with a2 (same roundings). */
 int maai_conv_bwd3_rows(long long M);
 int maai_conv_bwd3(const void* g, const void* y3, const void* y2, const void* wd, const float* k1, const float* k2, const float* k3,
-                   const float* mean2, const float* s2, const float* t2, void* dx, float* slab, float* dw, long long M, void* stream);
+                   const float* mean2, const float* s2, const float* t2, void* dx, float* slab, float* dw, long long M, int accumulate,
+                   void* stream);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d / nn.Linear):
  *   dw[co][kh][kw][ci] += sum_m dy[m][co] * x[n, oh*s-ph+kh, ow*s-pw+kw, ci]

@@ -5,11 +5,10 @@
 // The unfused sequence (apply-on-load data gradient + weight gradient) writes dz3 (6.6 GB at 224^2 x 256 images) only for
 // the weight gradient to read it back; here g and y3 are read once and dz3 exists only in registers and LDS.
 //
-// One workgroup per CU, 4 waves, 128 pixel rows per tile, tiles strided over the grid.  conv3's weights (32 KB, data-gradient
-// form) stay in LDS for the whole launch; the weight gradient is accumulated in registers (wave w owns output channels
-// 64w .. 64w+63 of dW3: 64 fp32 registers) and flushed with fp32 atomics once at the end.  Per tile: g, y3 (A layout of the
-// MFMA: a lane holds 8 channels of one pixel) and y2 arrive in registers — the NEXT tile's loads are issued before this
-// tile is processed (one wave per SIMD: 512 registers), so the kernel streams; dz3 is formed in place, written pixel-major
+// Persistent workgroups (two per CU, 4 waves, 64 pixel rows per tile, tiles strided over the grid).  conv3's weights (32 KB,
+// data-gradient form) stay in LDS for the whole launch; the weight gradient is accumulated in registers (wave w owns output
+// channels 64w .. 64w+63 of dW3: 64 fp32 registers) and flushed with fp32 atomics once at the end.  Per tile: g, y3 (A layout
+// of the MFMA: a lane holds 8 channels of one pixel) and y2 arrive in registers; dz3 is formed in place, written pixel-major
 // to LDS (the weight gradient reads it transposed, ds_read_b64_tr_b16) and multiplied from registers by the resident weights
 // (no barrier in that loop); the epilogue masks by y2*s2 + t2 > 0, stores dx, adds bn2's sums and drops a2 = relu(r(y2*s2 +
 // t2)) into LDS for the weight gradient.  All vector-memory traffic is compiler-visible loads / stores: no manual vmcnt.
@@ -30,21 +29,22 @@ struct Bwd3Args {
   const float* s2;
   const float* t2;
   void* dx;          // [M][64]
+  int accumulate;    // dx += (the shortcut branch of a projection block adds to the main branch's gradient, in place)
   float* slab;       // [gridDim][2][64]
   float* dw;         // [256][64] fp32, += (zeroed by the caller)
   long long M;
   int ntiles;
 };
 
-// TM: 16-row MFMA tiles per wave (the workgroup's tile has BM = 64*TM pixel rows).
-// PF: one workgroup per CU that prefetches the next tile's operands into a second register set; otherwise two workgroups
-// per CU overlap each other's phases (TM = 1 only: the wave's C staging area IS its 16 rows of the a2 image — each row is
-// read back as chunks before the same lanes overwrite it with a2 — which brings LDS under 80 KB).
-template <int TM, bool PF>
-__global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) {
+// Two workgroups per CU overlap each other's phases (a one-workgroup variant that prefetched the next tile's operands into a
+// second register set measured 4.7 vs 3.75 ms).  64-row tiles, 16 rows per wave: the wave's C staging area IS its 16 rows of
+// the a2 image — each row is read back as chunks before the same lanes overwrite it with a2 — which keeps LDS under 80 KB.
+// ACC: dx += (in place).
+template <bool ACC>
+__global__ __launch_bounds__(256, 2) void conv_bwd3_kernel(Bwd3Args a) {
   typedef bf16_t T;
-  static_assert(PF || TM == 1, "the aliased C area needs one 16-row group per wave");
-  constexpr int KC = 256, NC = 64, KT = KC / 32, TN = NC / 16, LDC = PF ? NC + 8 : NC, CW = 16 * LDC * 2, RB = 128, BM = 64 * TM;
+  constexpr int TM = 1;
+  constexpr int KC = 256, NC = 64, KT = KC / 32, TN = NC / 16, LDC = NC, CW = 16 * LDC * 2, RB = 128, BM = 64 * TM;
   constexpr int WSM = KT * 4096, DZT = 4 * BM * RB, A2T = BM * RB;
   typedef Mma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
   char* dzt = smem + WSM;            // four [BM rows][64 ch] sub-tiles of dz3 (128-byte rows, swizzled for transposed reads)
   char* a2t = dzt + DZT;             // [BM rows][64 ch]
   float* coef = reinterpret_cast<float*>(a2t + A2T);     // k1 | k2 | k3 (256 each)
-  char* cws = PF ? reinterpret_cast<char*>(coef + 3 * KC) : a2t;   // wave-private C areas
+  char* cws = a2t;                   // wave-private C areas (see above)
   float* red = reinterpret_cast<float*>(dzt);            // [4 waves][2][64]: after the last tile
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
   char* cw = cws + widu * CW;
   const uint32_t cwa = (uint32_t)(uintptr_t)(cw + ((gl * 4) * LDC + li) * 2);
 
-  auto load_tile = [&](int t, uint4 (&G)[TM][KT], uint4 (&Y)[TM][KT], uint4 (&Y2)[TM][2]) {
+  auto load_tile = [&](int t, uint4 (&G)[TM][KT], uint4 (&Y)[TM][KT], uint4 (&Y2)[TM][2], uint4 (&P)[ACC ? TM : 1][2]) {
     const long long row0 = (long long)t * BM + widu * (16 * TM);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -118,11 +118,12 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
         long long m2r = row0 + i * 16 + er + 8 * it;
         if (m2r >= a.M) m2r = a.M - 1;
         Y2[i][it] = *reinterpret_cast<const uint4*>(y2p + m2r * NC + ec * 8);
+        if constexpr (ACC) P[i][it] = *reinterpret_cast<const uint4*>(dx + m2r * NC + ec * 8);
       }
     }
   };
 
-  auto process = [&](int t, uint4 (&G)[TM][KT], uint4 (&Y)[TM][KT], uint4 (&Y2)[TM][2]) {
+  auto process = [&](int t, uint4 (&G)[TM][KT], uint4 (&Y)[TM][KT], uint4 (&Y2)[TM][2], uint4 (&P)[ACC ? TM : 1][2]) {
     const long long row0 = (long long)t * BM + widu * (16 * TM);
     // everyone has finished the weight-gradient reads of the previous tile's LDS images (and, first tile, the tables are in)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -200,6 +201,14 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
         float fv[8], fy[8];
         v.get(fv);
         vy.get(fy);
+        if constexpr (ACC) {
+          Vec16<T> vp;
+          vp.raw = P[i][it];
+          float fo[8];
+          vp.get(fo);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fo[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) fv[e] = (fy[e] * sc2[e] + sh2[e]) > 0.f ? fv[e] : 0.f;
         v.set(fv);
@@ -249,25 +258,11 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
 
   // ---- tiles strided over the grid ----
   const int G = gridDim.x;
-  if constexpr (PF) {   // the next tile's operands in flight while this one is processed
-    uint4 GA[TM][KT], YA[TM][KT], Y2A[TM][2], GB[TM][KT], YB[TM][KT], Y2B[TM][2];
-    int t = blockIdx.x;
-    if (t < a.ntiles) load_tile(t, GA, YA, Y2A);
-    while (t < a.ntiles) {
-      const int tn = t + G;
-      if (tn < a.ntiles) load_tile(tn, GB, YB, Y2B);
-      process(t, GA, YA, Y2A);
-      if (tn >= a.ntiles) break;
-      const int tnn = tn + G;
-      if (tnn < a.ntiles) load_tile(tnn, GA, YA, Y2A);
-      process(tn, GB, YB, Y2B);
-      t = tnn;
-    }
-  } else {
-    uint4 GA[TM][KT], YA[TM][KT], Y2A[TM][2];
+  {
+    uint4 GA[TM][KT], YA[TM][KT], Y2A[TM][2], PA[ACC ? TM : 1][2];
     for (int t = blockIdx.x; t < a.ntiles; t += G) {
-      load_tile(t, GA, YA, Y2A);
-      process(t, GA, YA, Y2A);
+      load_tile(t, GA, YA, Y2A, PA);
+      process(t, GA, YA, Y2A, PA);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -309,43 +304,35 @@ __global__ __launch_bounds__(256, PF ? 1 : 2) void conv_bwd3_kernel(Bwd3Args a) 
 }
 
 // g, y3: [M][256]; y2: [M][64]; wd: conv3's weights as [64][256] (data-gradient form); k1..k3 [256]; mean2, s2, t2 [64];
-// dx [M][64]; slab [*slab_rows][2][64] (rows = workgroups launched, returned by maai_conv_bwd3_rows); dw [256][64] fp32 +=.
-constexpr int kBwd3TM = 1;   // 64-row tiles
-
-static bool bwd3_prefetch() {   // MAAI_BWD3_PF = 0 | 1 (experiment knob, read per call)
-  const char* e = getenv("MAAI_BWD3_PF");
-  return e ? atoi(e) != 0 : false;
-}
-
+// dx [M][64] (accumulate != 0: += in place, the sums are those of the stored result); slab [*slab_rows][2][64] (rows = workgroups launched, returned by maai_conv_bwd3_rows); dw [256][64] fp32 +=.
 extern "C" int maai_conv_bwd3_rows(long long M) {
-  const long long tiles = (M + 64 * kBwd3TM - 1) / (64 * kBwd3TM);
+  const long long tiles = (M + 63) / 64;
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long wgs = (long long)cus * (bwd3_prefetch() ? 1 : 2);
+  const long long wgs = 2LL * cus;
   return (int)(tiles < wgs ? tiles : wgs);
 }
 
 extern "C" int maai_conv_bwd3(const void* g, const void* y3, const void* y2, const void* wd, const float* k1, const float* k2,
                               const float* k3, const float* mean2, const float* s2, const float* t2, void* dx, float* slab,
-                              float* dw, long long M, void* stream) {
+                              float* dw, long long M, int accumulate, void* stream) {
   MAAI_CHECK_ARG(g && y3 && y2 && wd && k1 && k2 && k3 && mean2 && s2 && t2 && dx && slab && dw && M > 0, "conv_bwd3: null pointer");
   MAAI_CHECK_ARG(M < (1ll << 31), "conv_bwd3: pixel count must fit 31 bits");
-  constexpr int BM = 64 * kBwd3TM;
+  constexpr int BM = 64;
   Bwd3Args a;
   a.g = g; a.y3 = y3; a.y2 = y2; a.wd = wd; a.k1 = k1; a.k2 = k2; a.k3 = k3; a.mean2 = mean2; a.s2 = s2; a.t2 = t2;
-  a.dx = dx; a.slab = slab; a.dw = dw; a.M = M; a.ntiles = (int)((M + BM - 1) / BM);
-  constexpr int lds0 = 8 * 4096 + 4 * BM * 128 + BM * 128 + 3 * 256 * 4;
+  a.dx = dx; a.accumulate = accumulate; a.slab = slab; a.dw = dw; a.M = M; a.ntiles = (int)((M + BM - 1) / BM);
+  constexpr int lds = 8 * 4096 + 4 * BM * 128 + BM * 128 + 3 * 256 * 4;
   const int grid = maai_conv_bwd3_rows(M);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static int attr_a[64] = {0}, attr_b[64] = {0};
-  if (bwd3_prefetch()) {
-    constexpr int lds = lds0 + 4 * 16 * 72 * 2;
-    maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<kBwd3TM, true>), lds, attr_a);
-    hipLaunchKernelGGL((conv_bwd3_kernel<kBwd3TM, true>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  static int attr[2][64] = {{0}};
+  if (accumulate) {
+    maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<true>), lds, attr[0]);
+    hipLaunchKernelGGL((conv_bwd3_kernel<true>), dim3((unsigned)grid), dim3(256), lds, st, a);
   } else {
-    maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<kBwd3TM, false>), lds0, attr_b);
-    hipLaunchKernelGGL((conv_bwd3_kernel<kBwd3TM, false>), dim3((unsigned)grid), dim3(256), lds0, st, a);
+    maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<false>), lds, attr[1]);
+    hipLaunchKernelGGL((conv_bwd3_kernel<false>), dim3((unsigned)grid), dim3(256), lds, st, a);
   }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

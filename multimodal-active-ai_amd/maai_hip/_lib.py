@@ -48,7 +48,7 @@ SIGNATURES = {
     "maai_conv2d_stats_rows_fused": (c_ll, [_P_DESC, _P_EPI, c_i]),
     "maai_conv2d_igemm_fused": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, _P_EPI, c_i, c_p]),
     "maai_conv_bwd3_rows": (c_i, [c_ll]),
-    "maai_conv_bwd3": (c_i, [c_p] * 13 + [c_ll, c_p]),
+    "maai_conv_bwd3": (c_i, [c_p] * 13 + [c_ll, c_i, c_p]),
     "maai_conv2d_wgrad": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_wgrad_tuned": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_conv2d_wgrad_xf": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),

@@ -767,7 +767,7 @@ _BWD3 = {"enabled": os.environ.get("MAAI_BWD3", "1") != "0"}
 
 def _bwd3_applies(rec, dout, below, need_dx, dx_out, accumulate, relu_mask, dy):
     w = rec.conv.weight
-    return (_BWD3["enabled"] and dy is None and need_dx and dx_out is None and not accumulate and relu_mask is None
+    return (_BWD3["enabled"] and dy is None and need_dx and (dx_out is None) == (not accumulate) and relu_mask is None
             and dout.dtype == torch.bfloat16 and tuple(w.shape) == (256, 64, 1, 1) and rec.stride == 1 and rec.pad == 0
             and w.requires_grad and not rec.fused and rec.y is not None and rec.form == "fwd"
             and below is not None and below.relu and not below.has_res and below.y is not None and not below.fused
@@ -788,7 +788,7 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         #  finalises both of its BatchNorms in one exchange)
         k1, k2, k3 = coeffs if coeffs is not None else unit_bwd_coeffs(rec, dout, grads, dtype, presums)
         dx, slab, dw = K.conv_bwd3(dout, rec.y, below.y, w_dgrad(rec.conv.weight, dtype, [0], [0]), k1, k2, k3,
-                                   _reduce_mean(below), below.scale, below.shift)
+                                   _reduce_mean(below), below.scale, below.shift, dx=dx_out if accumulate else None)
         grads[id(rec.conv.weight)] = _grad_to_reference(rec, dw)
         return dx, K.reduce_partials(slab)
     fused_apply = dy is None and axf_applies(rec, dout, below, need_dx) and not any(
@@ -974,14 +974,18 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
     arbitrary tensor): the returned gradient is the plain d/dx.  Returns (dx, sums for ``prev`` or None)."""
     in_mask = (lambda: r1.x) if mask_input else (lambda: None)
     _, r1, r2, r3, rd = entry
-    dyd = None
+    dyd, kd_fused = None, False
     if rd is not None and _DUAL_BN["enabled"] and not r3.fused and not rd.fused:
         # both branches receive the same gradient: one pass reads it once and writes both dy
         k3, kd = _drive_pair(_unit_bwd_coeffs_gen(r3, dout, grads, dtype, presums), _unit_bwd_coeffs_gen(rd, dout, grads, dtype))
         below3 = r2 if r2 is not None else r1
         if _bwd3_applies(r3, dout, below3, True, None, False, None, None):
-            # the main branch's apply happens inside its fused backward launch: only the shortcut's is a pass
-            dyd, _ = K.bn_act_bwd_apply(dout, None, rd.y, kd[0], kd[1], kd[2], False, True, False)
+            # the main branch's apply happens inside its fused backward launch; so does the shortcut's where that launch
+            # takes it too (a stride-1 64 -> 256 projection whose input is a plain conv-bn-relu unit: ``kd_fused``)
+            kd_fused = (prev is not None and rd.stride == 1 and dout.shape[1:3] == tuple(rd.in_hw)
+                        and _bwd3_applies(rd, dout, prev, True, dout, True, None, None))
+            if not kd_fused:
+                dyd, _ = K.bn_act_bwd_apply(dout, None, rd.y, kd[0], kd[1], kd[2], False, True, False)
             d, s = unit_bwd(r3, dout, grads, dtype, below=below3, coeffs=k3)
         else:
             dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
@@ -1008,7 +1012,9 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
         else:
             # (a stride-1 shortcut's pass rewrites — and masks — every pixel: the first pass then needs no mask)
             dx, _ = unit_bwd(r1, d, grads, dtype, relu_mask=in_mask() if strided else None, presums=s)
-            if prev is not None:
+            if prev is not None and kd_fused:
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, coeffs=kd)
+            elif prev is not None:
                 dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
             else:
                 dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=in_mask(), dy=dyd)

@@ -321,22 +321,27 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     return out
 
 
-def conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2):
+def conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2, dx=None):
     """Backward of a 64 -> 256 bottleneck's conv3 + bn3 in one launch (csrc/conv_bwd3.hip): returns
-    (dx [N,H,W,64], slab [rows,2,64] of bn2's backward partial sums, dw [256,1,1,64] fp32)."""
-    _gpu(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2)
+    (dx [N,H,W,64], slab [rows,2,64] of bn2's backward partial sums, dw [256,1,1,64] fp32).  ``dx`` given: the data
+    gradient is ADDED to it in place (before the mask; the sums are those of the stored result)."""
+    _gpu(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2, dx)
     if not (g.dtype == y3.dtype == y2.dtype == wd.dtype == torch.bfloat16) or g.shape != y3.shape or g.shape[-1] != 256 or \
             y2.shape[-1] != 64 or y2.shape[:-1] != g.shape[:-1] or tuple(wd.shape) != (64, 1, 1, 256):
         raise MaaiError("conv_bwd3: g, y3 [..,256], y2 [..,64] and wd [64,1,1,256] in bf16")
     m = g.numel() // 256
     rows = int(lib().maai_conv_bwd3_rows(m))
-    dx = torch.empty_like(y2)
+    acc = dx is not None
+    if acc and (dx.shape != y2.shape or dx.dtype != y2.dtype or not dx.is_contiguous()):
+        raise MaaiError("conv_bwd3: dx must match y2")
+    if not acc:
+        dx = torch.empty_like(y2)
     slab = torch.empty((rows, 2, 64), dtype=torch.float32, device=g.device)
     dw = torch.zeros((256, 1, 1, 64), dtype=torch.float32, device=g.device)
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[bwd3] M%d Cin256 Cout64 k1x1 s1 os1 acc0" % m
-    with _timed(nm, 2.0 * m * 256 * 64 * 2, 2 * (2 * g.numel() + 2 * y2.numel() + wd.numel()), 2 * (g.numel() + y2.numel())):
+    with _timed(nm, 2.0 * m * 256 * 64 * 2, 2 * (2 * g.numel() + (3 if acc else 2) * y2.numel() + wd.numel()), 2 * (g.numel() + y2.numel())):
         check(lib().maai_conv_bwd3(_p(g), _p(y3), _p(y2), _p(wd), _p(k1), _p(k2), _p(k3), _p(mean2), _p(s2), _p(t2), _p(dx), _p(slab),
-                                   _p(dw), m, _stream()), "maai_conv_bwd3")
+                                   _p(dw), m, 1 if acc else 0, _stream()), "maai_conv_bwd3")
     return dx, slab, dw
 
 

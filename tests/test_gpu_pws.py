@@ -170,8 +170,9 @@ def test_chained_block_boundary_matches_unchained(K, case, pre_lazy, shortcut, k
     assert torch.equal(got[0], y1r) and torch.equal(got[2], jor) and torch.equal(got[3], jbr)
 
 
+@pytest.mark.parametrize("acc", [False, True], ids=["store", "accumulate"])
 @pytest.mark.parametrize("case", [(2, 16, 16), (3, 15, 15), (1, 9, 11), (1, 56, 56), (4, 30, 30)], ids=lambda c: "x".join(map(str, c)))
-def test_fused_conv3_backward_matches_the_two_launches(K, case):
+def test_fused_conv3_backward_matches_the_two_launches(K, case, acc):
     """conv3 + bn3 backward of a 64 -> 256 bottleneck in one persistent launch (csrc/conv_bwd3.hip: BatchNorm-backward
     apply, data gradient with bn2's mask and sums, weight gradient; dz3 never written) against the sequence it replaces —
     the apply-on-load data gradient that keeps dz3, then the weight gradient on the lazy input (resnet.py:118-119 backward)."""
@@ -185,13 +186,14 @@ def test_fused_conv3_backward_matches_the_two_launches(K, case):
     mean2 = (torch.randn(64, generator=g_) * 0.1).cuda()
     s2, t2 = (torch.rand(64, generator=g_) + 0.5).cuda(), (torch.randn(64, generator=g_) * 0.3).cuda()
     m = n * h * w_
-    dx0 = torch.empty_like(y2)
+    prev = torch.randn(n, h, w_, 64, generator=g_).cuda().bfloat16()   # (accumulate: the other branch's gradient)
+    dx0 = prev.clone() if acc else torch.empty_like(y2)
     part0 = torch.zeros((m + 127) // 128, 2, 64, device="cuda")
     dz = torch.empty_like(g)
-    K.conv2d_store_reduce(g, wd, 1, 0, 0, dx0, part0, y2, mean2, s2, t2, None, axf=(y3, k1, k2, k3, dz))
+    K.conv2d_store_reduce(g, wd, 1, 0, 0, dx0, part0, y2, mean2, s2, t2, None, accumulate=acc, axf=(y3, k1, k2, k3, dz))
     dw0 = K.conv2d_wgrad(K.Lazy(y2, s2, t2, True), dz, 1, 1, 1, 0, 0)
-    dx1, part1, dw1 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2)
-    dx2, part2, dw2 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2)
+    dx1, part1, dw1 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2, dx=prev.clone() if acc else None)
+    dx2, part2, dw2 = K.conv_bwd3(g, y3, y2, wd, k1, k2, k3, mean2, s2, t2, dx=prev.clone() if acc else None)
     torch.cuda.synchronize()
     assert torch.equal(dx0, dx1) and torch.equal(dx1, dx2)
     t0, t1 = part0.double().sum(0), part1.double().sum(0)
