@@ -60,7 +60,7 @@ def family(name):
     """conv_igemm_kernel<bf16, 256, 128, 3, 6, false, true> -> conv_igemm (the names bench.py's table uses: every
     convolution / data-gradient launch, ring or streaming kernel, is "conv_igemm"; every weight gradient "conv_wgrad")."""
     base = name.split("<")[0]
-    for a, b in (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
+    for a, b in (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("conv_chain_kernel", "conv_igemm"), ("conv_bwd3_kernel", "conv_igemm"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
                  ("bn_act_fwd2_kernel", "bn_act_fwd"), ("bn_act_fwd_kernel", "bn_act_fwd"), ("bn_bwd_apply2_kernel", "bn_bwd_apply"),
                  ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
                  ("reduce_partials_kernel", "reduce_partials")):
