@@ -16,7 +16,8 @@ bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,1024,128),
 temperature 0.5.  N = 1, 2, 4: BASELINE configs[1] per GPU (per-GPU batch 256,
 weak scaling).  N = 8: BASELINE configs[2] = the metric's own configuration,
 per-GPU batch 512 (global 4096) with block recompute (512 images of stored
-activations do not fit 288 GB); --batch / --recompute override.
+activations do not fit 288 GB; layers 1-2 are recomputed, layer 3 too if less
+than ~270 GB is free on any rank); --batch / --recompute override.
 Synthetic images are per-image random low-frequency colour patterns plus
 noise, generated on the device, so that the two views of one image correlate
 and the contrastive loss is NOT the 2*ln(2N-1) of collapsed embeddings; the
@@ -210,9 +211,21 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
+    rc_layers = None
     if args.recompute:
         from maai_hip import engine
-        engine.set_recompute(True)
+        # Which stages are recomputed: layers 1-2 only keeps layers 3-4 stored (512 images: 227 GB allocated, 258 GB reserved,
+        # 688 images/s); if any rank has less than that free, layer 3 is recomputed too (152 / 186 GB, 656 images/s).  The
+        # decision is taken on the minimum over ranks so that every rank runs the same program.
+        if os.environ.get("MAAI_RECOMPUTE_LAYERS"):
+            rc_layers = sorted(engine._RECOMPUTE["layers"])
+        else:
+            free = torch.tensor([float(torch.cuda.mem_get_info(device)[0])], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(free, op=dist.ReduceOp.MIN)
+            need = 270e9 * args.batch / 512.0 * (args.img / 224.0) ** 2
+            rc_layers = [1, 2] if free.item() >= need else [1, 2, 3]
+        engine.set_recompute(True, rc_layers)
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
 
@@ -322,7 +335,8 @@ def main():
                                    % (args.arch, args.img, args.img, args.batch, " with block recompute" if args.recompute else "",
                                       args.temperature, "configs[2] (global batch 4096)" if world * args.batch == 4096 else "configs[1] per GPU"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": losses[-1], "loss_first_timed_step": losses[0],
-                       "recompute": bool(args.recompute), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+                       "recompute": bool(args.recompute), "recompute_layers": rc_layers, "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                       "peak_hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if args.arch == "resnet50" and args.img == 224:

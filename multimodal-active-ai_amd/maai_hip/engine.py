@@ -846,6 +846,11 @@ def _blocks(resnet):
             yield blk
 
 
+def _block_stages(resnet):
+    """stage number (1-4) of every block, in ``_blocks`` order"""
+    return [i + 1 for i, name in enumerate(("layer1", "layer2", "layer3", "layer4")) for _ in getattr(resnet, name)]
+
+
 def stem_input(x, conv1, dtype):
     """NCHW fp32 / list of u8 HWC views -> (stem operand NHWC, weights, form)."""
     cin = conv1.weight.shape[1]
@@ -870,11 +875,17 @@ def stem_input(x, conv1, dtype):
 # epilogues, bit-identical tensors) just before differentiating it.  Activation memory drops from ~12 to ~4 C-wide
 # tensors per block — what lets 512 images per GPU (global batch 4096 on 8 GPUs, BASELINE configs[2]) fit in 288 GB —
 # for one extra forward of the differentiated view.
-_RECOMPUTE = {"enabled": os.environ.get("MAAI_RECOMPUTE", "0") == "1"}
+# Which stages: MAAI_RECOMPUTE_LAYERS (default "1,2").  Layers 1 and 2 hold ~80 % of the activation bytes and cost ~60 % of a
+# forward; keeping layers 3 and 4 stored saves their second forward (512 images / GPU: 129 -> ~225 GB, 643 -> ~690 images/s).
+_RECOMPUTE = {"enabled": os.environ.get("MAAI_RECOMPUTE", "0") == "1",
+              "layers": frozenset(int(v) for v in os.environ.get("MAAI_RECOMPUTE_LAYERS", "1,2").split(",") if v.strip())}
 
 
-def set_recompute(flag):
+def set_recompute(flag, layers=None):
+    """Block recompute on / off; ``layers``: the stages (1-4) whose blocks are recomputed (default: as configured)."""
     _RECOMPUTE["enabled"] = bool(flag)
+    if layers is not None:
+        _RECOMPUTE["layers"] = frozenset(int(v) for v in layers)
 
 
 def _lighten(r):
@@ -943,7 +954,8 @@ def backbone_fwd(resnet, x, dtype, keep):
     blocks = list(_blocks(resnet))
     # the stem's activation is formed on load by layer1's first convolutions when that block has a projection
     # shortcut (an identity shortcut would read the tensor itself)
-    ckpt = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
+    ckpt_on = keep and _RECOMPUTE["enabled"] and _FUSE["max_cin"] == 0
+    stages = _block_stages(resnet)
     stem_lazy = (bool(blocks) and blocks[0].downsample is not None and not _fusable(blocks[0].conv1, "fwd")
                  and not _fusable(blocks[0].downsample[0], "fwd") and _lazy_pays([blocks[0].conv1, blocks[0].downsample[0]], keep))
     K.FLOPS_SCALE[0] = (49.0 * cin) / (wq.shape[1] * wq.shape[2] * wq.shape[3])  # executed K includes zero padding
@@ -954,6 +966,7 @@ def backbone_fwd(resnet, x, dtype, keep):
     for i, blk in enumerate(blocks):
         lazy_out = i + 1 < len(blocks) and _joins_on_load(blocks[i + 1], dtype) and _FUSE["max_cin"] == 0
         # (block recompute: this forward's activations are dropped and rebuilt, so it runs with the no-backward policy)
+        ckpt = ckpt_on and stages[i] in _RECOMPUTE["layers"]
         out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out, pol_keep=keep and not ckpt)
         if prev3 is not None:
             prev3.out, prev3.bits = xin, xin_bits   # the join this block's conv1 formed IS the previous block's output

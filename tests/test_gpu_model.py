@@ -527,8 +527,9 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
     assert res["join"][2] <= res["lazy"][2]
 
 
+@pytest.mark.parametrize("layers", [(1, 2), (1, 2, 3, 4), (3, 4)], ids=["stages12", "all-stages", "stages34"])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
-def test_block_recompute_matches_stored_activations(mods, prec):
+def test_block_recompute_matches_stored_activations(mods, prec, layers):
     """engine.set_recompute: the backward re-runs each block's forward from its saved input and BN statistics.
     Same features bit for bit, far fewer bytes held between forward and backward, same gradients up to the
     summation order of the BN-backward sums (those of a block's last unit no longer ride the epilogue above it),
@@ -539,7 +540,7 @@ def test_block_recompute_matches_stored_activations(mods, prec):
     x = _u8(6, (4, 3, 32, 32)).float().cuda()
     res = {}
     for tag in ("stored", "recompute"):
-        engine.set_recompute(tag == "recompute")
+        engine.set_recompute(tag == "recompute", layers)   # (recomputed and stored stages may meet in either order)
         try:
             m = _build(mods, "resnet50", 1, 2048 * 16, 4, (32, 32), 0.5)
             m.train()
@@ -572,9 +573,9 @@ def test_block_recompute_matches_stored_activations(mods, prec):
             res[tag] = (feat.float().cpu(), named, held, m.f.layer2[0].bn2.running_var.clone().cpu(),
                         int(m.f.layer2[0].bn2.num_batches_tracked))
         finally:
-            engine.set_recompute(False)
+            engine.set_recompute(False, (1, 2))
     assert torch.equal(res["stored"][0], res["recompute"][0])
-    assert res["recompute"][2] < 0.6 * res["stored"][2], (res["recompute"][2], res["stored"][2])
+    assert res["recompute"][2] < (0.6 if 1 in layers else 0.9) * res["stored"][2], (res["recompute"][2], res["stored"][2])
     assert torch.equal(res["stored"][3], res["recompute"][3]) and res["stored"][4] == res["recompute"][4] == 1
     assert res["stored"][1].keys() == res["recompute"][1].keys()
     for n, gp in res["stored"][1].items():
