@@ -458,7 +458,7 @@ def unit_fwd(*args, **kwargs):
 
 
 def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None,
-                  lazy_out=False, side=None):
+                  lazy_out=False, side=None, light=False):
     """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).  A generator: with SyncBatchNorm over
     more than one rank it yields its local fp64 sums once and resumes with the all-reduced ones (``_drive``);
     ``branch`` may be a one-element list filled in before that resumption (``_drive_pair``).
@@ -470,7 +470,9 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     branch whose normalisation is applied by the unit it is added to; ``branch`` = such a (y2, scale2, shift2)
     triple, applied and added in this unit's single BN pass (maai_bn_act_fwd2) in place of ``residual``.
     ``given``: a record of an earlier run of this very unit (block recompute): its statistics are reused, the
-    convolution runs without a statistics epilogue and the running buffers are left alone."""
+    convolution runs without a statistics epilogue and the running buffers are left alone.
+    ``light``: the record will only be kept for its statistics (the first forward of a recomputed block): the unit may
+    then be chained into its consumer exactly as in a forward without a backward pass."""
     _check_conv(conv)
     k = conv.kernel_size[0]
     stride, pad = conv.stride[0], conv.padding[0]
@@ -510,7 +512,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     y = None
     # chained block boundary: this convolution is not run here (training: only its statistics are taken) — the next block's
     # first convolution recomputes it inside the launch that joins it with the shortcut
-    chain = (lazy_out and not keep and not fused and not eval_fused and not defer and given is None and form == "fwd"
+    chain = (lazy_out and (not keep or light) and not fused and not eval_fused and not defer and given is None and form == "fwd"
              and (residual is not None or branch is not None) and _chain_ok(conv, x, dtype))
     if given is not None:
         training = given.training
@@ -566,7 +568,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
     bits = None
-    want_bits = (keep and relu and (residual is not None or branch is not None) and y.dtype == torch.bfloat16
+    want_bits = (keep and y is not None and relu and (residual is not None or branch is not None) and y.dtype == torch.bfloat16
                  and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"])
     if defer:
         if relu or residual is not None or branch is not None:
@@ -915,6 +917,7 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
     side = {}
     if pol_keep is None:
         pol_keep = keep   # does a weight gradient read this forward's activations? (not when the block is recomputed)
+    light = keep and not pol_keep and given is None   # records kept for their statistics only
     needs_identity = blk.downsample is None
     if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or (xin.b is not None and not _joins_on_load(blk, dtype))):
         xin = materialise(xin)   # the identity shortcut reads it / conv1 cannot join it
@@ -935,14 +938,14 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
         # SyncBatchNorm the two units' statistics travel in ONE all-reduce (_drive_pair)
         box = [None]
         gen_d = _unit_fwd_gen(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, defer=True, given=gd)
-        gen_3 = _unit_fwd_gen(o, last_conv, last_bn, True, None, dtype, keep, branch=box, given=g3, lazy_out=lazy_out)
+        gen_3 = _unit_fwd_gen(o, last_conv, last_bn, True, None, dtype, keep, branch=box, given=g3, lazy_out=lazy_out, light=light)
         (br, rd), (out, r3) = _drive_pair(_Boxed(gen_d, box), gen_3)
     else:
         if blk.downsample is not None:
             idn, rd = unit_fwd(xin, blk.downsample[0], blk.downsample[1], False, None, dtype, keep, given=gd)
         else:
             idn = xin
-        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep, given=g3, lazy_out=lazy_out)
+        out, r3 = unit_fwd(o, last_conv, last_bn, True, idn, dtype, keep, given=g3, lazy_out=lazy_out, light=light)
     return out, (r1, r2, r3, rd), xin, xin_bits
 
 
