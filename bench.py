@@ -2,7 +2,9 @@
 """SimCLR ResNet-50 training-step benchmark on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started WITHOUT
+     a launcher — no WORLD_SIZE in the environment — bench.py starts that launcher itself as a child process, before
+     anything touches the GPU, and exits with its return code)
 
 One step = one pass of the hot path over one per-GPU batch of synthetic source
 images already resident in HBM (reference --num-fixations 1
@@ -15,9 +17,11 @@ Workload: ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224,
 bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,1024,128),
 temperature 0.5.  N = 1, 2, 4: BASELINE configs[1] per GPU (per-GPU batch 256,
 weak scaling).  N = 8: BASELINE configs[2] = the metric's own configuration,
-per-GPU batch 512 (global 4096) with block recompute (512 images of stored
-activations do not fit 288 GB; layers 1-2 are recomputed, layer 3 too if less
-than ~270 GB is free on any rank); --batch / --recompute override.
+per-GPU batch 512 (global 4096) with block recompute of stages 1-2 (512 images
+of stored activations do not fit 288 GB); the program is fixed by the flags —
+never by a free-memory probe — so every rank and every run executes the same
+launches (MAAI_RECOMPUTE_LAYERS=1,2,3 names other stages); --batch /
+--recompute / --no-recompute override.
 Synthetic images are per-image random low-frequency colour patterns plus
 noise, generated on the device, so that the two views of one image correlate
 and the contrastive loss is NOT the 2*ln(2N-1) of collapsed embeddings; the
@@ -43,7 +47,7 @@ for d in (ROOT, PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"))
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): dense bf16 MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r02_pmc_traffic_b256.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/profile_round.sh)
+PMC_SUMMARY = "r03_pmc_traffic_b256.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/profile_round.sh)
 
 
 def csrc_digest():
@@ -77,11 +81,35 @@ def parse():
                     help="block recompute in the backward (fits --batch 512 = global 4096 on 8 GPUs in 288 GB; one extra forward)")
     ap.add_argument("--no-recompute", action="store_true")
     args = ap.parse_args()
+    if args.recompute and args.no_recompute:
+        ap.error("--recompute and --no-recompute are contradictory")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
     if args.batch <= 0:
         args.batch = 512 if args.gpus >= 8 else 256
-        if args.gpus >= 8 and not args.no_recompute:
-            args.recompute = True
+    # 512 images per GPU at 224 px do not fit without block recompute: on by default from there on
+    if args.batch * (args.img / 224.0) ** 2 >= 512 and not args.no_recompute:
+        args.recompute = True
     return args
+
+
+def self_launch(args):
+    """``python3 bench.py --gpus N`` (N > 1) without a launcher: start ``python -m torch.distributed.run`` with the same
+    arguments as a CHILD process and return its exit code.  Called before anything in this process has touched the GPU
+    (and the GPU is never touched here afterwards: the parent only waits)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def build(args, device, world):
@@ -186,12 +214,16 @@ def cpu_baseline(args):
         sys.stderr.flush()
     med = statistics.median(times)
     return dict(value=round(b / med, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%s 3x%dx%d, batch %d, median of %d steps after 1 warm-up step (fp32, torch-CPU oracle); step times %s s"
-                       % (args.arch, args.img, args.img, b, args.cpu_steps, ["%.1f" % t for t in times]))
+                sample="%s 3x%dx%d, batch %d, median of %d steps after 1 warm-up step (fp32, torch-CPU oracle); step times %s s; "
+                       "bounded sample: BASELINE.md section 3 asks for 3 warm-up + >= 10 timed CPU steps (~2 min here), this default "
+                       "run keeps 1 + %d so that bench.py finishes within minutes (--cpu-steps 10 runs the full protocol)"
+                       % (args.arch, args.img, args.img, b, args.cpu_steps, ["%.1f" % t for t in times], args.cpu_steps))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,22 +241,17 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d (start it as `python3 bench.py --gpus N`, or under "
+                         "torch.distributed.run --nproc-per-node N)" % (world, args.gpus))
 
     rc_layers = None
     if args.recompute:
         from maai_hip import engine
-        # Which stages are recomputed: layers 1-2 only keeps layers 3-4 stored (512 images: 227 GB allocated, 258 GB reserved,
-        # 688 images/s); if any rank has less than that free, layer 3 is recomputed too (152 / 186 GB, 656 images/s).  The
-        # decision is taken on the minimum over ranks so that every rank runs the same program.
-        if os.environ.get("MAAI_RECOMPUTE_LAYERS"):
-            rc_layers = sorted(engine._RECOMPUTE["layers"])
-        else:
-            free = torch.tensor([float(torch.cuda.mem_get_info(device)[0])], dtype=torch.float64, device=device)
-            if world > 1:
-                dist.all_reduce(free, op=dist.ReduceOp.MIN)
-            need = 270e9 * args.batch / 512.0 * (args.img / 224.0) ** 2
-            rc_layers = [1, 2] if free.item() >= need else [1, 2, 3]
+        # Which stages are recomputed is part of the command, not of the machine's state: stages 1-2 (they hold ~80 % of
+        # the activation bytes; layers 3-4 stay stored and are not run a second time) unless MAAI_RECOMPUTE_LAYERS says
+        # otherwise.  Every rank of every run executes the same program.
+        rc_layers = sorted(engine._RECOMPUTE["layers"]) if os.environ.get("MAAI_RECOMPUTE_LAYERS") else [1, 2]
         engine.set_recompute(True, rc_layers)
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
@@ -316,6 +343,7 @@ def main():
             if k and summary.get("csrc_digest") == csrc_digest():
                 roof["traffic"] = round(k["hbm_bytes_per_launch"] / 1e9, 3)
                 roof["traffic_unit"] = "GB/launch (PMC, profiles/%s)" % PMC_SUMMARY
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(roof["algorithmic_GB_per_launch"], 1e-9), 3)
     if rank == 0 and args.profile_table:
         with open(args.profile_table, "w") as fh:
             json.dump({k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in table.items()}, fh, indent=1)

@@ -28,7 +28,7 @@ extern "C" {
 #define MAAI_BF16 0
 #define MAAI_F32 1
 
-#define MAAI_ABI_VERSION 3
+#define MAAI_ABI_VERSION 4
 
 int maai_abi_version(void);
 const char* maai_last_error(void);
@@ -198,6 +198,15 @@ int maai_reduce_partials(const float* partial, long long rows, int C2, double* s
 int maai_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                      float* shift, int C, void* stream);
+/* SyncBatchNorm exchange in fp32 (nn.SyncBatchNorm as selected at Contrastive_Learning.py:240-252; torch gathers
+ * mean | invstd | count per layer): maai_bn_pack_stats turns a rank's fp64 sums over `count` samples into
+ * packed[2C+1] = mean[C] | M2[C] = sum (x - mean)^2 | count (bit pattern of an int32); after an all-gather,
+ * maai_bn_finalize_gathered merges the `world` rows (row r at gathered + r*row_stride, row_stride >= 2C+1 floats)
+ * with Chan's parallel-variance formula in fp64 and produces what maai_bn_finalize produces. */
+int maai_bn_pack_stats(const double* sums, double count, float* packed, int C, void* stream);
+int maai_bn_finalize_gathered(const float* gathered, int world, long long row_stride, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                              float* scale, float* shift, int C, void* stream);
 /* eval mode: scale/shift from running statistics */
 int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* scale, float* shift, int C, void* stream);
@@ -235,6 +244,9 @@ int maai_bn_act_bwd_reduce(const void* dout, const void* out, const void* y, con
  *   dy = k1*dz - k2 - k3*y,  k1 = gamma*invstd, k3 = k1*invstd^2*S2/count, k2 = k1*S1/count - k3*mean */
 int maai_bn_bwd_coeffs(const double* sums, double count, const float* gamma, const float* mean, const float* invstd,
                        float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, void* stream);
+/* the same from fp32 sums (the cross-rank all-reduce of SyncBatchNorm's backward travels in fp32) */
+int maai_bn_bwd_coeffs_f32(const float* sums, double count, const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, void* stream);
 /* backward pass 2: dz = dout*(out>0); dy = k1[c]*dz - k2[c] - k3[c]*y; optional
  * dz_out (gradient of the residual input) written too. k* nullable -> dy = dz. */
 int maai_bn_act_bwd_apply(const void* dout, const void* out, const void* y, const float* k1, const float* k2,
@@ -323,6 +335,10 @@ typedef struct {
 } maai_adam_slot;
 int maai_adam_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
                          double lr, double beta1, double beta2, double eps, int step, float grad_scale, void* stream);
+/* torch.optim.SGD (Model_Util.py:70-73) for every tensor of a parameter group in one launch: slots as above with m = the
+ * momentum buffer (v unused); identical arithmetic to maai_sgd_step. */
+int maai_sgd_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                        float lr, float momentum, float weight_decay, int first_step, void* stream);
 
 /* LARC (Model_Util.py:80-83: `--optimizer lars` = apex.parallel.LARC around Adam; Apex's published algorithm,
  * trust_coefficient 0.02, clip mode — parity UNPINNED, Apex cannot be installed here).  slots / block maps as in

@@ -154,6 +154,79 @@ extern "C" int maai_bn_finalize(const double* sums, double count, const float* g
   return MAAI_OK;
 }
 
+// ---------------------------------------------------------------------------
+// SyncBatchNorm exchange in fp32: every rank sends  mean[C] | M2[C] | count  (M2 = sum (x - mean)^2 over ITS samples; the
+// count travels as the bit pattern of an int32, gathers do no arithmetic) — 2C+1 words, all well scaled, unlike the raw
+// sums of squares — and every rank merges the gathered rows with Chan's parallel-variance formula in fp64:
+//   N = sum n_r,  mean = sum n_r mean_r / N,  M2 = sum (M2_r + n_r (mean_r - mean)^2),  var = M2 / N.
+// (nn.SyncBatchNorm gathers mean | invstd | count per layer the same way; Contrastive_Learning.py:240-252 selects it.)
+// ---------------------------------------------------------------------------
+__global__ void bn_pack_stats_kernel(const double* __restrict__ sums, double count, float* __restrict__ packed, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  if (c == C) {
+    packed[2 * C] = __int_as_float((int)count);
+    return;
+  }
+  const double mean = sums[c] / count;
+  double m2 = sums[C + c] - count * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  packed[c] = (float)mean;
+  packed[C + c] = (float)m2;
+}
+
+extern "C" int maai_bn_pack_stats(const double* sums, double count, float* packed, int C, void* stream) {
+  MAAI_CHECK_ARG(sums && packed && C > 0 && count > 0 && count < 2147483648.0, "bn_pack_stats: bad arguments");
+  hipLaunchKernelGGL(bn_pack_stats_kernel, dim3((C + 256) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums, count,
+                     packed, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+__global__ void bn_finalize_gathered_kernel(const float* __restrict__ g, int world, long long row_stride,
+                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                            float* running_var, float momentum, float eps, float* mean_o, float* invstd_o,
+                                            float* scale_o, float* shift_o, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double N = 0.0, S = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double n = (double)__float_as_int(g[r * row_stride + 2 * C]);
+    N += n;
+    S += n * (double)g[r * row_stride + c];
+  }
+  const double mean = S / N;
+  double M2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double n = (double)__float_as_int(g[r * row_stride + 2 * C]);
+    const double d = (double)g[r * row_stride + c] - mean;
+    M2 += (double)g[r * row_stride + C + c] + n * d * d;
+  }
+  double var = M2 / N;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float gm = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  if (mean_o) mean_o[c] = (float)mean;
+  if (invstd_o) invstd_o[c] = (float)invstd;
+  scale_o[c] = (float)((double)gm * invstd);
+  shift_o[c] = (float)((double)b - mean * (double)gm * invstd);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unb = N > 1.0 ? var * (N / (N - 1.0)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int maai_bn_finalize_gathered(const float* gathered, int world, long long row_stride, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                         float* mean, float* invstd, float* scale, float* shift, int C, void* stream) {
+  MAAI_CHECK_ARG(gathered && scale && shift && C > 0 && world > 0 && row_stride >= 2LL * C + 1, "bn_finalize_gathered: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_gathered_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     gathered, world, row_stride, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       float* scale, float* shift, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,7 +479,8 @@ extern "C" int maai_bn_act_bwd_reduce(const void* dout, const void* out, const v
   return MAAI_OK;
 }
 
-__global__ void bn_bwd_coeffs_kernel(const double* __restrict__ sums, double count, const float* gamma, const float* mean,
+template <typename TS>   // TS: double (local / fp64-reduced sums) or float (the fp32 cross-rank exchange)
+__global__ void bn_bwd_coeffs_kernel(const TS* __restrict__ sums, double count, const float* gamma, const float* mean,
                                      const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
                                      int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -426,7 +500,17 @@ extern "C" int maai_bn_bwd_coeffs(const double* sums, double count, const float*
                                   const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
                                   void* stream) {
   MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel<double>, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
+                     count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
+extern "C" int maai_bn_bwd_coeffs_f32(const float* sums, double count, const float* gamma, const float* mean,
+                                      const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
+                                      void* stream) {
+  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && count > 0, "bn_bwd_coeffs_f32: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
                      count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

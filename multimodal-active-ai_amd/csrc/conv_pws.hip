@@ -14,16 +14,20 @@
 // Same MFMA sequence per output element as conv_igemm_kernel (K ascending, 32 per instruction): identical bits.
 #include "conv_igemm.h"
 
+// The wait in front of every K-step's barrier.  vmcnt(N): the step's weight stage has landed.  lgkmcnt(0): every LDS read
+// this wave has issued — the fragment reads of the previous step among them — has returned, so the slot that is refilled
+// right after the barrier is provably no longer being read by anyone, wherever hipcc schedules the (register-only) MFMAs of
+// the unrolled K loop (the "memory" clobber keeps the ds_read instructions themselves on their side of this statement).
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
 // KC = Cin; BN = column tile; DIST = weight stages in flight ahead of the one being multiplied (a stage = 32 input
 // channels x BN output channels).  The ring has DIST + 2 slots: the slot refilled after the barrier of step s is the
-// one read in step s-2, whose MFMAs every wave has ISSUED (hence whose LDS reads have returned) before it reached the
-// barrier of step s-1 — safe wherever the compiler schedules the MFMAs of step s-1 around the barrier of step s (the
-// K loop is fully unrolled here and hipcc does sink them below it, with their fragment reads still outstanding).
+// one read in step s-2.  That its reads are over is enforced, not left to instruction scheduling: every wave drains its
+// LDS reads (lgkmcnt(0), wait_vm above) before each barrier — the K loop is fully unrolled and hipcc does sink the MFMAs
+// of a step below the next barrier, which raced on a DIST + 1 ring before the drain existed; the spare slot is kept.
 // EMODE 0: plain store (+ statistics slab); 1: statistics slab only (the chained launch of conv_chain.hip recomputes the tensor).
 template <int KC, int BN, int DIST, int XF, int EMODE>
 __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {

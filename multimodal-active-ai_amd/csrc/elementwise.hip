@@ -449,6 +449,36 @@ extern "C" int maai_sgd_step(float* p, const float* g, float* mom, long long n, 
   return MAAI_OK;
 }
 
+// every tensor of a parameter group in one launch (slots: p, g, m = momentum buffer, v unused, n); arithmetic of sgd_kernel
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const maai_adam_slot* __restrict__ slots, const int* __restrict__ block_slot,
+                                                        const long long* __restrict__ block_first, float lr, float momentum, float wd,
+                                                        int first) {
+  const maai_adam_slot s = slots[block_slot[blockIdx.x]];
+  const long long i0 = block_first[blockIdx.x];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long long i = i0 + u * 256 + threadIdx.x;
+    if (i < s.n) {
+      float d = s.g[i] + wd * s.p[i];
+      if (momentum != 0.f) {
+        const float b = first ? d : momentum * s.m[i] + d;
+        s.m[i] = b;
+        d = b;
+      }
+      s.p[i] -= lr * d;
+    }
+  }
+}
+
+extern "C" int maai_sgd_step_multi(const maai_adam_slot* slots, const int* block_slot, const long long* block_first, int nblocks,
+                                   float lr, float momentum, float weight_decay, int first_step, void* stream) {
+  MAAI_CHECK_ARG(slots && block_slot && block_first && nblocks > 0, "sgd_step_multi: bad arguments");
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(nblocks), dim3(256), 0, ST(stream), slots, block_slot, block_first, lr, momentum,
+                     weight_decay, first_step);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 // ---------------------------------------------------------------------------
 // augmentation (replaces NVIDIA_DALI_Pipelines.py:444-480 for the north-star path)
 // ---------------------------------------------------------------------------

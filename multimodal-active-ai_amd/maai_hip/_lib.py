@@ -62,6 +62,9 @@ SIGNATURES = {
     "maai_bn_bwd_rows": (c_ll, [c_ll, c_i, c_i]),
     "maai_bn_act_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_bn_bwd_coeffs": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_bwd_coeffs_f32": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_pack_stats": (c_i, [c_p, c_d, c_p, c_i, c_p]),
+    "maai_bn_finalize_gathered": (c_i, [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_bn_act_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_pack_views_u8": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "maai_stem_unroll_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
@@ -79,6 +82,7 @@ SIGNATURES = {
     "maai_ntxent_normalize_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_d, c_d, c_d, c_d, c_i, c_f, c_p]),
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
+    "maai_sgd_step_multi": (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
     "maai_multi_sqnorm": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "maai_larc_scale": (c_i, [c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
     "maai_softmax_ce_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
@@ -95,7 +99,7 @@ class MaaiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
+ABI_VERSION = 4   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
 
 
 def _autobuild():

@@ -122,6 +122,11 @@ def drop_prefetched():
 # gradient averaging, overlapped with the backward pass
 # ----------------------------------------------------------------------------
 class GradReducer(object):
+    """Bucketed gradient averaging.  Every bucket carries, behind the gradient data, one PRESENCE word per parameter (1.0
+    where this rank produced a gradient): after the all-reduce it holds the number of ranks that did.  A parameter that
+    got a gradient on some ranks only is then averaged and written back on EVERY rank (a rank without one receives a new
+    tensor), so the replicas apply the same update; one that got none anywhere stays without (``None``)."""
+
     def __init__(self, params, bucket_bytes=32 << 20, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
@@ -136,8 +141,17 @@ class GradReducer(object):
             self.buckets.append(cur)
         self._flat = [None] * len(self.buckets)
         self._next = 0          # first bucket not yet launched in the current backward
-        self._inflight = []     # (work, flat, views, grads)
+        self._inflight = []     # (work, flat, views, tensors, bucket)
         self.launched_early = 0  # buckets launched from inside the backward pass (diagnostics / tests)
+
+    @staticmethod
+    def _producer_streams(grads):
+        """streams other than the compute stream that gradients in ``grads`` were produced on (the engine's weight-gradient
+        side stream, MAAI_WGRAD_SIDE_STREAM=1): the communication stream has to wait for them too"""
+        if grads is not None and grads.get("_side"):
+            from . import engine
+            return [engine._side_stream()]
+        return []
 
     # -- called by the engine while the backward pass runs ---------------------------------------------------
     def ready(self, grads):
@@ -145,48 +159,63 @@ class GradReducer(object):
         if not is_distributed():
             return
         while self._next < len(self.buckets) and all(id(p) in grads and grads[id(p)] is not None for p in self.buckets[self._next]):
-            self._launch(self._next, [grads[id(p)] for p in self.buckets[self._next]])
+            self._launch(self._next, [grads[id(p)] for p in self.buckets[self._next]], self._producer_streams(grads))
             self._next += 1
             self.launched_early += 1
             STATS["buckets_early"] += 1
 
     def finish(self, grads=None):
-        """Launch what is left (missing gradients count as zeros: they are then not written back), wait for every
-        bucket on the side stream, average, copy back; the compute stream continues behind the side stream."""
+        """Launch what is left (a gradient missing on this rank travels as zeros with presence 0), wait for every bucket
+        on the side stream, average, copy back; the compute stream continues behind the side stream.  Returns
+        {id(param): tensor} of the gradients this rank did not have but other ranks did (also put into ``grads``)."""
         if not is_distributed():
             self._next = 0
-            return
+            return {}
         while self._next < len(self.buckets):
             tensors = []
             for p in self.buckets[self._next]:
                 g = None if grads is None else grads.get(id(p))
                 tensors.append(g)
-            self._launch(self._next, tensors)
+            self._launch(self._next, tensors, self._producer_streams(grads))
             self._next += 1
             STATS["buckets_late"] += 1
         world = dist.get_world_size(self.group)
         dev = self.params[0].device
         side = comm_stream(dev)
         ctx = torch.cuda.stream(side) if side is not None else _Null()
+        created = {}
         with ctx:
-            for work, flat, views, tensors in self._inflight:
+            for work, flat, views, tensors, bucket in self._inflight:
                 work.wait()
-                flat.mul_(1.0 / world)
+                n = sum(p.numel() for p in bucket)
+                flat[:n].mul_(1.0 / world)
                 dst = [t for t in tensors if t is not None]
                 src = [v.view_as(t) for v, t in zip(views, tensors) if t is not None]
                 if dst:
                     torch._foreach_copy_(dst, src)
+                if len(dst) != len(tensors):
+                    # (only a rank that is missing gradients reads the presence counts: one host read, off the common path)
+                    counts = flat[n:n + len(bucket)].tolist()
+                    for p, v, t, c in zip(bucket, views, tensors, counts):
+                        if t is None and c > 0.5:
+                            created[id(p)] = v.view_as(p).clone()
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
+            for t in created.values():
+                t.record_stream(torch.cuda.current_stream(dev))
+        if grads is not None:
+            grads.update(created)
         self._inflight = []
         self._next = 0
+        return created
 
-    def _launch(self, i, tensors):
+    def _launch(self, i, tensors, producers=()):
         bucket = self.buckets[i]
         dev = self.params[0].device
         n = sum(p.numel() for p in bucket)
-        if self._flat[i] is None or self._flat[i].numel() != n or self._flat[i].device != dev:
-            self._flat[i] = torch.empty(n, dtype=torch.float32, device=dev)
+        total = n + len(bucket)   # gradient data | one presence word per parameter
+        if self._flat[i] is None or self._flat[i].numel() != total or self._flat[i].device != dev:
+            self._flat[i] = torch.empty(total, dtype=torch.float32, device=dev)
         flat = self._flat[i]
         views, off = [], 0
         for p in bucket:
@@ -195,19 +224,25 @@ class GradReducer(object):
         side = comm_stream(dev)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dev))   # the gradient kernels are enqueued on the compute stream
+            for st in producers:
+                side.wait_stream(st)                           # ... or on the engine's weight-gradient stream
         ctx = torch.cuda.stream(side) if side is not None else _Null()
         with ctx:
             have = [(v, t) for v, t in zip(views, tensors) if t is not None]
             if len(have) != len(views):
-                flat.zero_()
+                flat[:n].zero_()
             if have:
                 torch._foreach_copy_([v.view_as(t) for v, t in have], [t.detach() for _, t in have])
+            if len(have) == len(views):
+                flat[n:].fill_(1.0)
+            else:
+                flat[n:].copy_(torch.tensor([0.0 if t is None else 1.0 for t in tensors], dtype=torch.float32), non_blocking=False)
             work = dist.all_reduce(flat, group=self.group, async_op=True)
         if side is not None:
             for t in tensors:
                 if t is not None:
                     t.record_stream(side)
-        self._inflight.append((work, flat, views, tensors))
+        self._inflight.append((work, flat, views, tensors, bucket))
 
     # -- the whole exchange after a backward that ran without the hook --------------------------------------
     def __call__(self):
@@ -216,7 +251,10 @@ class GradReducer(object):
             return
         grads = {id(p): p.grad for p in self.params if p.grad is not None}
         self._next = 0
-        self.finish(grads)
+        created = self.finish(grads)
+        for p in self.params:
+            if id(p) in created:
+                p.grad = created[id(p)]
 
 
 class _Null(object):

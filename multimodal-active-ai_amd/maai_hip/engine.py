@@ -379,17 +379,46 @@ def _lazy_input_ok(x, conv, dtype):
     return True
 
 
-def _drive(gen, reduce=True):
-    """Run a unit generator to completion; it yields its local fp64 sums at most once when a cross-rank exchange is
-    due and continues with the reduced ones."""
+# SyncBatchNorm exchanges travel in fp32 (2C+1 / 2C words, <= 16 KB: latency-bound messages).  A unit generator yields
+# ("gather", packed) — its mean | M2 | count row (kernels.bn_pack_stats) — in the forward pass and resumes with the
+# [world, 2C+1] matrix of every rank's row, or ("reduce", sums) — fp32 sums of the BatchNorm backward — and resumes with
+# their all-reduced values.  EXCHANGES counts the collectives issued (the per-step latency budget).
+EXCHANGES = {"gather": 0, "reduce": 0}
+
+
+def _exchange(kind, vecs):
+    """ONE collective for all of ``vecs`` (same kind): returns the per-vector results, in order."""
+    flat = vecs[0] if len(vecs) == 1 else torch.cat(vecs)
+    EXCHANGES[kind] += 1
+    if kind == "gather":
+        world = dist.get_world_size()
+        out = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
+        dist.all_gather_into_tensor(out, flat.contiguous())
+        res, o = [], 0
+        for v in vecs:
+            res.append(out[:, o:o + v.numel()])
+            o += v.numel()
+        return res
+    if kind != "reduce":
+        raise MaaiError("unknown exchange %r" % (kind,))
+    dist.all_reduce(flat)     # (the vectors are fresh fp32 copies of the units' fp64 sums: nothing of a caller's is reduced in place)
+    res, o = [], 0
+    for v in vecs:
+        res.append(flat[o:o + v.numel()])
+        o += v.numel()
+    return res
+
+
+def _drive(gen):
+    """Run a unit generator to completion; it yields (kind, vector) at most once when a cross-rank exchange is due and
+    continues with the exchanged result."""
     try:
-        sums = next(gen)
+        kind, vec = next(gen)
     except StopIteration as e:
         return e.value
-    if reduce:
-        dist.all_reduce(sums)
+    got = _exchange(kind, [vec])[0]
     try:
-        gen.send(sums)
+        gen.send(got)
     except StopIteration as e:
         return e.value
     raise MaaiError("a unit asked for more than one statistics exchange")
@@ -397,25 +426,26 @@ def _drive(gen, reduce=True):
 
 def _drive_pair(ga, gb):
     """Two units whose statistics are due at the same point (the two BatchNorms that meet at a projection shortcut,
-    forward and backward): ONE all-reduce over both sum vectors instead of two."""
+    forward and backward): ONE collective over both vectors instead of two."""
     ra = rb = None
-    sa = sb = None
+    ya = yb = None
     try:
-        sa = next(ga)
+        ya = next(ga)
     except StopIteration as e:
         ra = (e.value,)
     try:
-        sb = next(gb)
+        yb = next(gb)
     except StopIteration as e:
         rb = (e.value,)
-    if sa is not None and sb is not None:
-        both = torch.cat([sa, sb])
-        dist.all_reduce(both)
-        sa, sb = both[:sa.numel()], both[sa.numel():]
-    elif sa is not None:
-        dist.all_reduce(sa)
-    elif sb is not None:
-        dist.all_reduce(sb)
+    sa = sb = None
+    if ya is not None and yb is not None:
+        if ya[0] != yb[0]:
+            raise MaaiError("paired units asked for different kinds of exchange")
+        sa, sb = _exchange(ya[0], [ya[1], yb[1]])
+    elif ya is not None:
+        sa = _exchange(ya[0], [ya[1]])[0]
+    elif yb is not None:
+        sb = _exchange(yb[0], [yb[1]])[0]
     for which, g, sm in ((0, ga, sa), (1, gb, sb)):
         if sm is None:
             continue
@@ -460,7 +490,7 @@ def unit_fwd(*args, **kwargs):
 def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd", defer=False, branch=None, given=None,
                   lazy_out=False, side=None, light=False):
     """out = act(BN(conv(x)) (+ residual)); x NHWC.  Returns (out, rec or None).  A generator: with SyncBatchNorm over
-    more than one rank it yields its local fp64 sums once and resumes with the all-reduced ones (``_drive``);
+    more than one rank it yields ("gather", its packed mean | M2 | count row) once and resumes with every rank's rows (``_drive``);
     ``branch`` may be a one-element list filled in before that resumption (``_drive_pair``).
     ``x`` may be a ``kernels.Lazy`` activation (formed on load).  If it is a two-tensor join, the joined activation
     (and, bf16 with gradients, its 1-bit ReLU mask) comes back in ``side["joined"]`` / ``side["bits"]``.
@@ -529,9 +559,11 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             count = y.numel() // c
         sums = K.reduce_partials(part)
         world = _sync_world(bn)
+        gathered = None
         if world > 1:
-            sums = yield sums
-            count *= world
+            # one fp32 row per rank: mean | M2 | count, merged after the all-gather (Chan) — nn.SyncBatchNorm's protocol
+            gathered = yield ("gather", K.bn_pack_stats(sums, count))
+            count *= world   # (every rank runs the same per-GPU batch: what the backward's 1/count uses)
         mom = bn.momentum
         if bn.track_running_stats and bn.running_mean is not None:
             bn.num_batches_tracked += 1
@@ -541,7 +573,10 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         else:
             rm = rv = None
             mom = 0.0
-        mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
+        if gathered is not None:
+            mean, invstd, scale, shift = K.bn_finalize_gathered(gathered, bn.weight, bn.bias, rm, rv, mom, bn.eps)
+        else:
+            mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
         scale, shift = K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, _bn_eps(bn))
         if eval_fused:
@@ -742,7 +777,7 @@ def _unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums=None):
         if rec.world > 1:
             # torch SyncBatchNorm: weight/bias gradients from the LOCAL sums, dx from the all-reduced ones
             dgamma, dbeta, _, _, _ = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
-            sums = yield sums.clone() if presums is not None else sums   # (never all-reduce a caller's tensor in place)
+            sums = yield ("reduce", sums.float())   # fp32 on the wire (the local sums were taken in fp64)
             _, _, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)
         else:
             dgamma, dbeta, k1, k2, k3 = K.bn_bwd_coeffs(sums, rec.count, gamma, rec.mean, rec.invstd)

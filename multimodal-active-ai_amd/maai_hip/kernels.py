@@ -528,6 +528,30 @@ def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, e
     return mean, invstd, scale, shift
 
 
+def bn_pack_stats(sums, count):
+    """fp64 sums [2C] over ``count`` samples -> fp32 [2C+1]: mean | M2 | count (the SyncBatchNorm message of one rank)"""
+    _gpu(sums)
+    c = sums.numel() // 2
+    packed = torch.empty(2 * c + 1, dtype=torch.float32, device=sums.device)
+    check(lib().maai_bn_pack_stats(_p(sums), float(count), _p(packed), c, _stream()), "maai_bn_pack_stats")
+    return packed
+
+
+def bn_finalize_gathered(gathered, gamma, beta, running_mean, running_var, momentum, eps):
+    """``gathered``: [world, 2C+1] fp32 rows of ``bn_pack_stats`` (any row stride, unit column stride) -> what
+    ``bn_finalize`` returns for the merged statistics (Chan's parallel variance in fp64)."""
+    _gpu(gathered)
+    if gathered.dim() != 2 or gathered.dtype != torch.float32 or gathered.stride(1) != 1:
+        raise MaaiError("bn_finalize_gathered: expected a [world, 2C+1] fp32 matrix with contiguous rows")
+    world, c = gathered.shape[0], (gathered.shape[1] - 1) // 2
+    dev = gathered.device
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    check(lib().maai_bn_finalize_gathered(_p(gathered), world, gathered.stride(0), _p(gamma), _p(beta), _p(running_mean),
+                                          _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale),
+                                          _p(shift), c, _stream()), "maai_bn_finalize_gathered")
+    return mean, invstd, scale, shift
+
+
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     _gpu(running_mean, running_var)
     c = running_mean.numel()
@@ -596,11 +620,16 @@ def bn_act_bwd_reduce(dout, out, y, mean, relu):
 
 
 def bn_bwd_coeffs(sums, count, gamma, mean, invstd):
+    """``sums``: fp64 (local / reduced in fp64) or fp32 (the cross-rank exchange of SyncBatchNorm's backward)"""
     c = mean.numel()
     dev = mean.device
     dgamma, dbeta, k1, k2, k3 = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(5))
-    check(lib().maai_bn_bwd_coeffs(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
-                                   _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs")
+    if sums.dtype == torch.float32:
+        check(lib().maai_bn_bwd_coeffs_f32(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
+                                           _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs_f32")
+    else:
+        check(lib().maai_bn_bwd_coeffs(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
+                                       _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs")
     return dgamma, dbeta, k1, k2, k3
 
 
@@ -855,6 +884,39 @@ class AdamMulti(object):
         check(lib().maai_adam_step_multi(_p(self.table_dev), _p(self.block_slot), _p(self.block_first), self.nblocks, float(lr),
                                          float(beta1), float(beta2), float(eps), int(step), float(grad_scale), _stream()),
               "maai_adam_step_multi")
+
+
+class SgdMulti(object):
+    """One-launch SGD over a fixed list of fp32 tensors (maai_sgd_step_multi); block map as in AdamMulti."""
+    CHUNK = 2048
+
+    def __init__(self, params, moms):
+        import numpy as np
+        self.params, self.moms = list(params), list(moms)
+        _gpu(*self.params, *self.moms)
+        dev = self.params[0].device
+        slot, first = [], []
+        for i, p in enumerate(self.params):
+            nb = (p.numel() + self.CHUNK - 1) // self.CHUNK
+            slot.append(np.full(nb, i, dtype=np.int32))
+            first.append(np.arange(nb, dtype=np.int64) * self.CHUNK)
+        self.block_slot = torch.from_numpy(np.concatenate(slot)).to(dev)
+        self.block_first = torch.from_numpy(np.concatenate(first)).to(dev)
+        self.nblocks = int(self.block_slot.numel())
+        self.table = np.zeros((len(self.params), 5), dtype=np.int64)   # maai_adam_slot: p, g, m, v (unused), n
+        for i, (p, m) in enumerate(zip(self.params, self.moms)):
+            self.table[i, 0], self.table[i, 2], self.table[i, 4] = p.data_ptr(), m.data_ptr(), p.numel()
+        self.table_dev = torch.empty((len(self.params), 5), dtype=torch.int64, device=dev)
+
+    def step(self, grads, lr, momentum, weight_decay, first):
+        _gpu(*grads)
+        for i, g in enumerate(grads):
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.table[i, 4]:
+                raise MaaiError("sgd_step_multi: gradients must be contiguous fp32 tensors of the parameter's size")
+            self.table[i, 1] = g.data_ptr()
+        self.table_dev.copy_(torch.from_numpy(self.table), non_blocking=False)
+        check(lib().maai_sgd_step_multi(_p(self.table_dev), _p(self.block_slot), _p(self.block_first), self.nblocks, float(lr),
+                                        float(momentum), float(weight_decay), 1 if first else 0, _stream()), "maai_sgd_step_multi")
 
 
 class LarcMulti(object):

@@ -27,16 +27,20 @@ def gather_one(z, world_size, group=None):
     return out
 
 
-def prefetch_embedding(h):
+def prefetch_embedding(h, _normalize=None):
     """Start the all-gather of normalize(h) on the side stream (maai_hip.dist.prefetch_embedding); a later
-    contrastive_loss(h.data, ...) / contrastive_loss(..., h) with hidden_norm=True picks it up."""
+    contrastive_loss(h.data, ...) / contrastive_loss(..., h) with hidden_norm=True picks it up.
+    (``_normalize``: tests substitute the normalisation kernel, e.g. to inject a failure on one rank.)"""
+    if _normalize is not None:
+        if D.is_distributed() and h.dim() == 2:
+            D.prefetch_embedding(h, _normalize)
+        return
     if D.is_distributed() and h.is_cuda and h.dim() == 2:
-        try:
-            D.prefetch_embedding(h, lambda t: K.ntxent_normalize(t, True))
-        except RuntimeError as e:   # the loss then gathers on the compute stream, as it does without a prefetch
-            D.STATS["prefetch_failed"] = D.STATS.get("prefetch_failed", 0) + 1
-            import warnings
-            warnings.warn("embedding prefetch failed (%s); falling back to the gather inside contrastive_loss" % e)
+        # Which collectives a step issues must be the same on every rank.  A failure here (say an out-of-memory error
+        # in the normalisation) is therefore NOT absorbed by a rank-local fallback to the in-loss gather — the other
+        # ranks would already have enqueued this [B,d] all-gather and the sequences would no longer pair up: the
+        # exception propagates and the job ends non-zero.
+        D.prefetch_embedding(h, lambda t: K.ntxent_normalize(t, True))
 
 
 class _NTXentFn(torch.autograd.Function):

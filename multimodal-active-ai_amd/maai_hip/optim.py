@@ -62,6 +62,7 @@ class HipSGD(torch.optim.Optimizer):
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._multi = {}   # per group: (key, kernels.SgdMulti) — one launch for all tensors of the group
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -69,7 +70,8 @@ class HipSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
+            live, firsts = [], set()
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -79,8 +81,26 @@ class HipSGD(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.zeros_like(p)
                     st["step"] = 0
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.sgd_step(p, g, st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"], first)
+                live.append(p)
+                firsts.add(first)
+            if not live:
+                continue
+            plain = all(p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in live)
+            if plain and len(firsts) == 1 and len(live) > 1:
+                # every tensor of the group in one launch (maai_sgd_step_multi: same arithmetic as the per-tensor kernel)
+                key = tuple((p.data_ptr(), self.state[p]["momentum_buffer"].data_ptr()) for p in live)
+                hit = self._multi.get(gi)
+                if hit is None or hit[0] != key:
+                    hit = (key, K.SgdMulti(live, [self.state[p]["momentum_buffer"] for p in live]))
+                    self._multi[gi] = hit
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+                hit[1].step(grads, group["lr"], group["momentum"], group["weight_decay"], firsts.pop())
+            else:
+                for p in live:
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    K.sgd_step(p, g, st["momentum_buffer"], group["lr"], group["momentum"], group["weight_decay"],
+                               st["step"] == 1)
         bump_weight_epoch()
         return loss
 

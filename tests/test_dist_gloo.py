@@ -71,6 +71,21 @@ def _worker(rank, world, port, q):
     red3.ready(g3)
     red3.finish(g3)
     extra["partial"] = (g3[id(params[0])].flatten()[0].item(), red3.launched_early, len(g3))
+    # a gradient that exists on rank 0 only: every rank ends up with the same average (rank 1 receives a new tensor), so the
+    # replicas cannot drift apart; one that exists nowhere stays absent
+    red4 = GradAllReduce(params, bucket_bytes=1 << 20)
+    g4 = {id(params[1]): torch.full_like(params[1], 4.0)}
+    if rank == 0:
+        g4[id(params[0])] = torch.full_like(params[0], 6.0)
+    red4.finish(g4)
+    extra["mixed"] = (g4[id(params[0])].flatten()[0].item(), tuple(g4[id(params[0])].shape), g4[id(params[1])].flatten()[0].item(),
+                      id(params[2]) in g4)
+    for p in params:
+        p.grad = None
+    if rank == 1:
+        params[2].grad = torch.full_like(params[2], 8.0)
+    red4()
+    extra["mixed_call"] = (params[2].grad.flatten()[0].item(), params[0].grad is None)
     # Utilities.reduce_tensor (SimCLR/Utilities.py:30-34): mean over ranks, argument untouched
     t = torch.tensor([float(rank + 1), 10.0 * (rank + 1)])
     r = Utilities.reduce_tensor(t, world)
@@ -108,6 +123,57 @@ def test_two_rank_gloo(golden_dir, world):
         np.testing.assert_allclose(extra["hook"], [1.5 * 10, 1.5 * 11, 1.5 * 12])
         assert extra["nbuckets"] == 2 and extra["early"] == [1, 1, 2], extra   # bucket 0 = the last parameter, bucket 1 = the other two
         assert extra["partial"] == (1.5, 0, 1)
+        assert extra["mixed"] == (3.0, (7, 3), 4.0, False), extra["mixed"]
+        assert extra["mixed_call"] == (4.0, True), extra["mixed_call"]
         assert extra["reduce_tensor"] == ([1.5, 15.0], [float(r + 1), 10.0 * (r + 1)])
         assert extra["prefetch"] and extra["prefetch_stale"]
     np.testing.assert_allclose(np.mean([x[1] for x in res]), G[f"w{world}_global_loss"], rtol=1e-6)
+
+
+def _failing_worker(rank, world, port, q):
+    """rank 1's normalisation raises before its all-gather is issued; rank 0's is already enqueued"""
+    import datetime
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-active-ai_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=20))
+    from oracle import simclr_oracle as O
+    from maai_hip import loss as L
+    from maai_hip import dist as D
+    h = torch.randn(8, 16)
+
+    def norm(v):
+        if rank == 1:
+            raise RuntimeError("injected: out of memory in the normalisation")
+        return O.l2_normalize(v), torch.ones(v.shape[0])
+    try:
+        L.prefetch_embedding(h, _normalize=norm)
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e)))
+        q.close()
+        q.join_thread()
+        os._exit(3)   # what an uncaught exception does to a rank: the job ends non-zero
+    # the healthy rank: its gather can never complete — it must end in an error, not in a mismatched collective
+    try:
+        got = D.take_prefetched(h.data, world)
+        q.put((rank, "completed", str(got is not None)))
+    except Exception as e:   # noqa: BLE001 (gloo reports the lost peer / the time-out)
+        q.put((rank, "peer_lost", type(e).__name__))
+    q.close()
+    q.join_thread()
+    os._exit(0)
+
+
+def test_prefetch_failure_on_one_rank_is_not_absorbed():
+    """a rank-local fallback would leave the ranks with different collective sequences.  The failing rank
+    must raise (and exit non-zero); the other rank must not silently pair its all-gather with something else."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_failing_worker, args=(r, 2, 29741, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict((r, (what, msg)) for r, what, msg in [q.get(timeout=120) for _ in ps])
+    [p.join(60) for p in ps]
+    assert res[1][0] == "raised" and "injected" in res[1][1], res
+    assert ps[1].exitcode == 3
+    assert res[0][0] == "peer_lost", res

@@ -487,6 +487,75 @@ def test_adam_multi_tensor_is_bit_identical(K):
     assert opt.state[ps[-1]]["step"] == 3
 
 
+def test_sgd_multi_tensor_is_bit_identical(K):
+    """HipSGD (Model_Util.py:70-73) updates all tensors of a group in one launch (maai_sgd_step_multi): same bits as the
+    per-tensor kernel, torch.optim.SGD(momentum, weight_decay) within rounding, ragged sizes."""
+    from maai_hip.optim import HipSGD
+    g = torch.Generator().manual_seed(13)
+    sizes = [(1,), (7, 3), (2048,), (2049,), (64, 3, 7, 7), (5000,)]
+    ps = [torch.nn.Parameter(torch.randn(sz, generator=g).cuda()) for sz in sizes]
+    single = [p.detach().clone() for p in ps]
+    moms = [torch.zeros_like(p) for p in single]
+    ref = [torch.nn.Parameter(p.detach().clone().cpu()) for p in ps]
+    opt, ropt = HipSGD(ps, lr=0.05, momentum=0.9, weight_decay=1e-4), torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        grads = [torch.randn(sz, generator=g) for sz in sizes]
+        for p, r, gr, q, m in zip(ps, ref, grads, single, moms):
+            p.grad, r.grad = gr.cuda(), gr.clone()
+            K.sgd_step(q, gr.cuda(), m, 0.05, 0.9, 1e-4, step == 0)
+        opt.step()
+        ropt.step()
+    assert len(opt._multi) == 1
+    for p, q, r in zip(ps, single, ref):
+        assert torch.equal(p.detach(), q)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert opt.state[ps[-1]]["step"] == 3
+
+
+@pytest.mark.parametrize("world,counts", [(1, [4096]), (2, [3000, 3000]), (8, [100, 7, 512, 512, 1, 9000, 33, 64])])
+def test_syncbn_packed_statistics_merge(K, world, counts):
+    """The fp32 SyncBatchNorm exchange (nn.SyncBatchNorm at Contrastive_Learning.py:240-252): per-rank mean | M2 | count
+    rows merged with Chan's formula == BatchNorm statistics of the concatenated samples (fp64), unequal counts and a large
+    mean/std ratio included; running statistics as torch updates them; non-contiguous rows (a column slice of a pair's
+    exchange) accepted."""
+    C = 96
+    g = torch.Generator().manual_seed(21 + world)
+    offs = torch.randn(C, generator=g) * 50.0       # |mean| / std up to ~150: raw sums of squares in fp32 would cancel
+    xs = [torch.randn(n, C, generator=g, dtype=torch.float64) * (torch.rand(C, generator=g, dtype=torch.float64) + 0.5) + offs.double() for n in counts]
+    rows = []
+    for x in xs:
+        sums = torch.cat([x.sum(0), (x * x).sum(0)]).cuda()
+        rows.append(K.bn_pack_stats(sums, x.shape[0]))
+    pad = torch.zeros(world, 5, device="cuda")
+    wide = torch.cat([pad, torch.stack(rows), pad], dim=1)          # rows at a stride != 2C+1
+    gathered = wide[:, 5:5 + 2 * C + 1]
+    assert not gathered.is_contiguous() or world == 1
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    mean, invstd, scale, shift = K.bn_finalize_gathered(gathered, gamma, beta, rm, rv, 0.1, 1e-5)
+    allx = torch.cat(xs)
+    n = allx.shape[0]
+    m_ref, v_ref = allx.mean(0), allx.var(0, unbiased=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), rtol=2e-7, atol=1e-6)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(v_ref + 1e-5)).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(scale.cpu().numpy(), (gamma.cpu().double() / torch.sqrt(v_ref + 1e-5)).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(shift.cpu().numpy(), (beta.cpu().double() - m_ref * gamma.cpu().double() / torch.sqrt(v_ref + 1e-5)).numpy(),
+                               rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * m_ref.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 + 0.1 * v_ref * n / max(n - 1, 1)).numpy(), rtol=2e-5)
+    # the single-rank message reproduces maai_bn_finalize on the raw sums
+    if world == 1:
+        sums = torch.cat([xs[0].sum(0), (xs[0] * xs[0]).sum(0)]).cuda()
+        ref = K.bn_finalize(sums, n, gamma, beta, None, None, 0.0, 1e-5)
+        np.testing.assert_allclose(scale.cpu().numpy(), ref[2].cpu().numpy(), rtol=2e-5)
+    # backward coefficients from fp32 sums == from fp64 sums
+    s64 = torch.randn(2 * C, generator=g, dtype=torch.float64).cuda() * 100
+    a = K.bn_bwd_coeffs(s64, n, gamma, mean, invstd)
+    b = K.bn_bwd_coeffs(s64.float(), n, gamma, mean, invstd)
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_augment_bit_exact(K):
     g = torch.Generator().manual_seed(12)
     imgs = torch.randint(0, 256, (6, 64, 48, 3), dtype=torch.uint8, generator=g)

@@ -183,6 +183,46 @@ def test_bf16_production_path_end_to_end_resnet18(mods):
     np.testing.assert_allclose(m.state_dict()[key].cpu().numpy(), ns[key].numpy(), rtol=2e-2)
 
 
+# ResNet-50 end to end in bf16 is ill-conditioned even at residual_gamma = 0.25 with 8 images (the CPU oracle's OWN bf16-storage
+# run differs from its fp32 run by 0.46 of max|z|, min cosine 0.55): the assertion is relative to that yardstick.
+R50_BF16_E2E = {"rel_over_oracle_gap": 2.5}
+
+
+def test_bf16_production_path_end_to_end_resnet50_reported(mods, record_property):
+    """the timed (bf16) mode END TO END on ResNet-50 — the reference's native 12x30x30 input through
+    SimCLR_Module.forward (SimCLR.py:23-31), residual_gamma = 0.25 (where the network is well conditioned: fp32 == fp64 to
+    1e-4, tests/test_oracle_golden.py) — against the oracle's storage="bf16" run on the same inputs.  The number is
+    REPORTED (printed, recorded as a test property, quoted in DESIGN section 2) and asserted with margin; per-block parity
+    (2^-6) is what test_every_block_teacher_forced pins."""
+    B = 8
+    views = [_u8(200 + k, (B, 30, 30, 3)) for k in range(4)]
+    sd = O.pattern_state_dict("resnet50", 4, 2048 * 16, residual_gamma=0.25)
+    x = O.pack_views(views, B, (30, 30))
+    z_ref = O.simclr_forward(sd, x, "resnet50", True, "bf16")
+    z_f32 = O.simclr_forward(sd, x, "resnet50", True, "fp32")
+    m = _build(mods, "resnet50", 4, 2048 * 16, B, (30, 30), 0.25)
+    m.train()
+    with torch.no_grad():
+        z = m([v.cuda() for v in views]).cpu()
+    rel = ((z - z_ref).abs().max() / z_ref.abs().max()).item()
+    cos = torch.nn.functional.cosine_similarity(z, z_ref, dim=1).min().item()
+    rel32 = ((z - z_f32).abs().max() / z_f32.abs().max()).item()
+    cos32 = torch.nn.functional.cosine_similarity(z, z_f32, dim=1).min().item()
+    orel = ((z_ref - z_f32).abs().max() / z_f32.abs().max()).item()   # the oracle's own bf16-vs-fp32 distance: the yardstick
+    l_ref = O.nt_xent(z_ref, z_ref.flip(0), 0.5)[0].item()
+    l_got = O.nt_xent(z, z.flip(0), 0.5)[0].item()
+    msg = ("R50 12x30x30 bf16 end to end (gamma 0.25): max|z - z_oracle_bf16|/max|z| = %.3e, min cos = %.5f; vs oracle fp32: %.3e, cos %.5f; "
+           "oracle bf16 vs oracle fp32: %.3e; NT-Xent on z: %.6f vs %.6f" % (rel, cos, rel32, cos32, orel, l_got, l_ref))
+    print(msg)
+    record_property("r50_bf16_e2e", msg)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "r50_bf16_e2e.txt"), "w") as fh:
+            fh.write(msg + "\n")
+    assert rel < R50_BF16_E2E["rel_over_oracle_gap"] * orel + 0.05, msg
+    assert abs(l_got - l_ref) / l_ref < 0.2, msg
+
+
 def _nchw(t):
     return t.float().cpu().permute(0, 3, 1, 2).contiguous()
 

@@ -171,11 +171,15 @@ def test_chained_block_boundary_matches_unchained(K, case, pre_lazy, shortcut, k
 
 
 @pytest.mark.parametrize("acc", [False, True], ids=["store", "accumulate"])
-@pytest.mark.parametrize("case", [(2, 16, 16), (3, 15, 15), (1, 9, 11), (1, 56, 56), (4, 30, 30)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(2, 16, 16), (3, 15, 15), (1, 9, 11), (1, 56, 56), (4, 30, 30), (4, 224, 224), (3, 223, 225)],
+                         ids=lambda c: "x".join(map(str, c)))
 def test_fused_conv3_backward_matches_the_two_launches(K, case, acc):
     """conv3 + bn3 backward of a 64 -> 256 bottleneck in one persistent launch (csrc/conv_bwd3.hip: BatchNorm-backward
     apply, data gradient with bn2's mask and sums, weight gradient; dz3 never written) against the sequence it replaces —
-    the apply-on-load data gradient that keeps dz3, then the weight gradient on the lazy input (resnet.py:118-119 backward)."""
+    the apply-on-load data gradient that keeps dz3, then the weight gradient on the lazy input (resnet.py:118-119 backward).
+    The 4x224x224 / 3x223x225 cases have 3136 / 2352 tiles for 512 persistent workgroups: every workgroup walks several
+    tiles (the top-of-tile barrier, the C area aliasing the a2 image on later tiles, dx accumulated across tiles, a ragged
+    last tile); tests/test_gpu_timed_size.py runs the 256-image size."""
     n, h, w_ = case
     g_ = torch.Generator().manual_seed(hash(case) % 10007 + 11)
     g = torch.randn(n, h, w_, 256, generator=g_).cuda().bfloat16()
