@@ -66,6 +66,10 @@ typedef struct {
 int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                       const void* relu_mask, int dtype, void* stream);
 long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
+/* Kernel family of a plain forward launch of this geometry: 0 ring / halo, 1 streaming, 2 ping-pong (8 waves, 256 x 256
+ * tiles).  The families sum the statistics slab in different orders (outputs are bit-identical); a caller that needs
+ * bit-reproducible statistics across input forms keeps a layer on one family. */
+int maai_conv2d_kernel_family(const maai_conv_desc* d, int dtype);
 
 /* Fused epilogues for the HBM-bound pointwise layers: the GEMM is cheap next to its output traffic, so it is
  * run twice instead of materialising the raw conv output (resnet.py:109-110,130-133: conv3 -> bn3 -> += identity

@@ -23,7 +23,11 @@ __device__ __forceinline__ void chain_wait_vm(int n) {   // wait until at most n
   switch (n < 0 ? 0 : (n > 23 ? 23 : n)) {                // (waiting for fewer than allowed is always safe)
   // (lgkmcnt(0): this wave's fragment reads of the previous step have returned before it enters the barrier that precedes
   //  the refill of their slot — the ring invariant is enforced here, not left to where hipcc puts the MFMAs)
+#if MAAI_EXP & 2   // A/B build without the drain
+#define MAAI_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+#else
 #define MAAI_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ") lgkmcnt(0)" ::: "memory"); break;
+#endif
     MAAI_WVM(0) MAAI_WVM(1) MAAI_WVM(2) MAAI_WVM(3) MAAI_WVM(4) MAAI_WVM(5) MAAI_WVM(6) MAAI_WVM(7) MAAI_WVM(8) MAAI_WVM(9)
     MAAI_WVM(10) MAAI_WVM(11) MAAI_WVM(12) MAAI_WVM(13) MAAI_WVM(14) MAAI_WVM(15) MAAI_WVM(16) MAAI_WVM(17) MAAI_WVM(18)
     MAAI_WVM(19) MAAI_WVM(20) MAAI_WVM(21) MAAI_WVM(22) MAAI_WVM(23)

@@ -178,6 +178,43 @@ static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
   return mode == 2 || d->Cout >= 2 * d->Cin || d->Cin == 256;
 }
 
+// The 8-wave ping-pong kernel (conv_pp.hip) takes the MFMA-bound bf16 layers with >= 256 output channels: the 3x3
+// convolutions of stages 3-4 and their data gradients.  Its statistics slab has one row per 256 pixels — the row count
+// conv_plan already gives these shapes (256-row tiles), so selecting it changes no slab shape.
+// MAAI_CONV_PP = 0 (off) | 1 (shape rule, default) | 2 (every shape the kernel is built for), read per call.
+static bool pp_forced() {
+  const char* e = getenv("MAAI_CONV_PP");
+  return e && atoi(e) == 2;
+}
+static bool pp_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype, const void* relu_mask) {
+  const char* e = getenv("MAAI_CONV_PP");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  if (mode == 1 && (getenv("MAAI_CONV_BM") || getenv("MAAI_CONV_BN") || getenv("MAAI_CONV_NSTAGE") || getenv("MAAI_CONV_HALO"))) return false;
+  const int emode = epi ? epi->mode : MAAI_EPI_STORE;
+  if (dtype != MAAI_BF16 || d->Cin % 64 || d->Cout % 128 || d->KH * d->KW > 32 || d->KH * d->KW * d->Cin < 128) return false;
+  if (d->out_stride != 1 || d->out_off_h || d->out_off_w || d->OH != d->OHg || d->OW != d->OWg) return false;
+  if ((long long)d->N * d->IH * d->IW * d->Cin >= (1ll << 31)) return false;
+  if (epi && (epi->xs || epi->xb || epi->a2 || epi->pre_x)) return false;
+  if (emode == MAAI_EPI_STORE) {
+    if (d->accumulate || relu_mask) return false;
+  } else if (emode != MAAI_EPI_DGRAD_REDUCE) {
+    return false;
+  }
+  if (mode == 2) return true;
+  // measured against the ring / halo / streaming kernels (scripts/pp_ab.py, 256 images, interleaved, bit-identical outputs):
+  //   3x3: 256->256@56 1.13 -> 0.94 ms, 512->512@28 0.98 -> 0.80, stride 2 256@112 1.12 -> 0.89, 512@56 1.02 -> 0.81;
+  //   data gradients (mask + sums epilogue) 256@56 1.36 -> 1.17, 512@28 1.12 -> 0.96;
+  //   1x1: 1024->256@56 0.57 -> 0.48, 2048->512@28 0.50 -> 0.41, 1024->512@56 1.02 -> 0.88, 1024->2048@28 0.95 -> 0.84,
+  //        512->256@112 1.30 -> 1.16; the channel-expanding ones lose (256->1024@56: 0.64 -> 0.81, streaming kernel) or tie
+  //        (512->2048@28 0.57 -> 0.56).
+  const char* r = getenv("MAAI_CONV_PP_RULE");   // experiment knob: bit 0 = 3x3 >= 256 channels, 1 = long-K 1x1, 2 = 128-channel 3x3
+  const int rule = r ? atoi(r) : 3;
+  if (d->KH * d->KW >= 9) return d->Cout % 256 == 0 ? (rule & 1) && d->Cin >= 256 : (rule & 4) && d->Cin >= 128;
+  if (d->KH * d->KW == 1) return (rule & 2) && d->Cout % 256 == 0 && d->Cin >= 512 && d->Cout <= 2 * d->Cin;
+  return false;
+}
+
 extern "C" int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                                  const void* relu_mask, int dtype, void* stream) {
   return maai_conv2d_igemm_fused(d, x, w, y, stats_partial, relu_mask, nullptr, dtype, stream);
@@ -282,6 +319,14 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   sel.dtype = dtype; sel.bm = plan.bm; sel.halo = plan.halo; sel.nstage = 3;
   sel.pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
   if (a.pre_x) return maai_conv_chain_launch(a, st);
+  // (the default rule's shapes are never the streaming kernel's; MAAI_CONV_PP=2 — tests, A/B runs — takes every shape it can)
+  if (pp_selected(d, epi, dtype, relu_mask) && (!pws || pp_forced())) {
+    if (!maai_conv_pp_supported(a, dtype)) {
+      maai_set_error("conv2d_igemm: internal: the ping-pong kernel's shape rule and its support test disagree");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    return maai_conv_pp_launch(a, st);
+  }
   if (pws) {
     if (!relu_mask) return maai_conv_pws_launch(a, st);
     plan.bm = 128;   // the slab rows promised for this shape (a masked launch never carries a join: 128-row tiles)
@@ -344,8 +389,24 @@ extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const
     return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   const ConvPlan p = conv_plan(d, dtype);
   if (epi && epi->xs && p.bm == 64) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  // (the ping-pong kernel: one row per 256 pixels; a relu mask is unknown here — masked STORE launches write no slab)
+  const bool pp = pp_selected(d, epi, dtype, nullptr);
+  const long long pprows = maai_conv_pp_rows(d->Cout);
+  if (pp && pp_forced()) return ((long long)d->N * d->OHg * d->OWg + pprows - 1) / pprows;
   if (pws_selected(d, epi, dtype)) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  if (pp) return ((long long)d->N * d->OHg * d->OWg + pprows - 1) / pprows;
   return p.nMB;
+}
+
+/* which kernel family a PLAIN forward launch (no epilogue descriptor, tensor input) of this geometry gets:
+ * 0 = ring / halo (conv_igemm.h), 1 = streaming (conv_pws.hip), 2 = ping-pong (conv_pp.hip).  Each family sums the BatchNorm
+ * partial statistics in its own order; the engine keeps a layer on ONE family whatever form its input has. */
+extern "C" int maai_conv2d_kernel_family(const maai_conv_desc* d, int dtype) {
+  if (!d) return 0;
+  const bool pp = pp_selected(d, nullptr, dtype, nullptr);
+  if (pp && pp_forced()) return 2;
+  if (pws_selected(d, nullptr, dtype)) return 1;
+  return pp ? 2 : 0;
 }
 
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {

@@ -874,3 +874,7 @@ int maai_conv_xf_launch(const ConvArgs& a, const ConvSel& sel, hipStream_t st);
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st);
 // conv_chain.hip: conv3 (recomputed) + BatchNorm + residual join + the next block's conv1 in one launch
 int maai_conv_chain_launch(const ConvArgs& a, hipStream_t st);
+// conv_pp.hip: the 8-wave ping-pong kernel (256 x 256 tiles, 64-deep K-tiles) for the MFMA-bound layers
+bool maai_conv_pp_supported(const ConvArgs& a, int dtype);
+int maai_conv_pp_rows(int Cout);
+int maai_conv_pp_launch(const ConvArgs& a, hipStream_t st);

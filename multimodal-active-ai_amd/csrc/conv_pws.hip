@@ -20,7 +20,11 @@
 // the unrolled K loop (the "memory" clobber keeps the ds_read instructions themselves on their side of this statement).
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+#if MAAI_EXP & 2   // A/B build without the drain (scripts/build_variant.sh nodrain "-DMAAI_EXP=2"): what the drain costs
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#endif
 }
 
 // KC = Cin; BN = column tile; DIST = weight stages in flight ahead of the one being multiplied (a stage = 32 input

@@ -15,6 +15,7 @@
 // ds_read_b32 of the pixel-major tile (pitch BC+16 words, conflict-free).
 #include "common.h"
 #include "maai_internal.h"
+#include "conv_ppw.h"
 #include <stdlib.h>
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -865,6 +866,21 @@ extern "C" int maai_conv2d_wgrad_xf(const maai_conv_desc* d, const void* x, cons
   a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
   a.xs = xs; a.xt = xt; a.x_relu = x_relu;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY") && !xs) {
+    // the 8-wave ping-pong kernel (conv_ppw.hip) for the MFMA-bound layers.  MAAI_WGRAD_PP = 0 (off) | 1 (shape rule,
+    // default) | 2 (every shape it is built for), read per call.
+    const char* e = getenv("MAAI_WGRAD_PP");
+    const int mode = e ? atoi(e) : 1;
+    if (mode != 0) {
+      PpwArgs p;
+      p.x = x; p.dy = dy; p.dw = dw; p.M = a.M;
+      p.N = a.N; p.IH = a.IH; p.IW = a.IW; p.Cin = a.Cin; p.Cout = a.Cout; p.KH = a.KH; p.KW = a.KW;
+      p.stride = a.stride; p.pad_h = a.pad_h; p.pad_w = a.pad_w; p.OH = a.OH; p.OW = a.OW;
+      p.nCoB = p.nKB = 0; p.pix_per_split = 0;
+      if (maai_wgrad_pp_supported(p) && (mode == 2 || (a.Cin >= 256 && !getenv("MAAI_WGRAD_PATCH") && !getenv("MAAI_WGRAD_TILE"))))
+        return maai_wgrad_pp_launch(p, st, target_blocks > 0 ? (target_blocks / 6 < 64 ? 64 : target_blocks / 6) : 0);
+    }
+  }
   if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY")) {
     if (wgrad_patch_applies(a)) return launch_wgrad_patch(a, st, target_blocks > 0 ? target_blocks / 3 : 0);
     return dispatch_wgrad_bf16(a, st, target_blocks);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "maai_device_count": (c_i, []),
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
+    "maai_conv2d_kernel_family": (c_i, [_P_DESC, c_i]),
     "maai_conv2d_stats_rows_fused": (c_ll, [_P_DESC, _P_EPI, c_i]),
     "maai_conv2d_igemm_fused": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, _P_EPI, c_i, c_p]),
     "maai_conv_bwd3_rows": (c_i, [c_ll]),

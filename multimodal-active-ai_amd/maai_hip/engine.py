@@ -392,8 +392,10 @@ def _exchange(kind, vecs):
     EXCHANGES[kind] += 1
     if kind == "gather":
         world = dist.get_world_size()
-        out = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
-        dist.all_gather_into_tensor(out, flat.contiguous())
+        n = flat.numel()
+        buf = torch.empty(world * n, dtype=flat.dtype, device=flat.device)   # (flat: what every backend's gather accepts)
+        dist.all_gather_into_tensor(buf, flat.contiguous())
+        out = buf.view(world, n)
         res, o = [], 0
         for v in vecs:
             res.append(out[:, o:o + v.numel()])
@@ -519,7 +521,10 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     rows_out = (x.shape[0] * ((x.shape[1] + 2 * pad - kh) // stride + 1) * ((x.shape[2] + 2 * pad_w - kw) // stride + 1))
     eval_fused = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
                   and wq.shape[0] % 64 == 0 and rows_out <= _EVAL_FUSE["max_rows"])
-    if isinstance(x, K.Lazy) and (fused or eval_fused or form != "fwd" or not _lazy_input_ok(x, conv, dtype)):
+    # (a layer stays on ONE kernel family whatever form its input has: the families sum the statistics slab in different
+    #  orders, and the ping-pong kernel of conv_pp.hip takes tensors only — a lazy input to one of its layers is materialised)
+    if isinstance(x, K.Lazy) and (fused or eval_fused or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
+                                  or K.conv_module_family(conv, x.shape[0], x.shape[1], x.shape[2], dtype) == 2):
         x = materialise(x)
         if side is not None:
             side["joined"] = x
@@ -935,12 +940,16 @@ def _is_bottleneck(blk):
     return hasattr(blk, "conv3")
 
 
-def _joins_on_load(blk, dtype):
-    """Can ``blk``'s first convolution form the previous block's residual join on load?"""
+def _joins_on_load(blk, dtype, in_shape=None):
+    """Can ``blk``'s first convolution form the previous block's residual join on load?  (``in_shape`` = (N, H, W) of the
+    block input: a conv1 that runs on the ping-pong kernel takes a tensor — the join is then an ordinary BatchNorm pass)"""
     c1 = blk.conv1
-    return (_LAZY["enabled"] and _LAZY["join"] and _is_bottleneck(blk) and c1.kernel_size == (1, 1) and c1.stride == (1, 1)
-            and c1.padding == (0, 0) and c1.in_channels <= (2048 if _LAZY["policy"] == "all" else 512)
-            and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0 and not _fusable(c1, "fwd"))
+    ok = (_LAZY["enabled"] and _LAZY["join"] and _is_bottleneck(blk) and c1.kernel_size == (1, 1) and c1.stride == (1, 1)
+          and c1.padding == (0, 0) and c1.in_channels <= (2048 if _LAZY["policy"] == "all" else 512)
+          and c1.in_channels % (32 if dtype == torch.bfloat16 else 16) == 0 and not _fusable(c1, "fwd"))
+    if ok and in_shape is not None and K.conv_module_family(c1, in_shape[0], in_shape[1], in_shape[2], dtype) == 2:
+        ok = False
+    return ok
 
 
 def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None):
@@ -954,7 +963,8 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
         pol_keep = keep   # does a weight gradient read this forward's activations? (not when the block is recomputed)
     light = keep and not pol_keep and given is None   # records kept for their statistics only
     needs_identity = blk.downsample is None
-    if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or (xin.b is not None and not _joins_on_load(blk, dtype))):
+    if isinstance(xin, K.Lazy) and ((xin.b is None and needs_identity) or
+                                    (xin.b is not None and not _joins_on_load(blk, dtype, tuple(xin.shape[:3])))):
         xin = materialise(xin)   # the identity shortcut reads it / conv1 cannot join it
     nxt = blk.conv2
     o, r1 = unit_fwd(xin, blk.conv1, blk.bn1, True, None, dtype, keep, given=g1, lazy_out=_lazy_pays([nxt], pol_keep), side=side)
@@ -1002,7 +1012,10 @@ def backbone_fwd(resnet, x, dtype, keep):
     tape.append(("stem", r))
     prev3 = None   # record of the previous block's last unit while its output is still a Lazy join
     for i, blk in enumerate(blocks):
-        lazy_out = i + 1 < len(blocks) and _joins_on_load(blocks[i + 1], dtype) and _FUSE["max_cin"] == 0
+        # (the next block's input = this block's output: its extent follows from this block's stride)
+        st_i = (blk.conv2 if _is_bottleneck(blk) else blk.conv1).stride[0]
+        nshape = (out.shape[0], (out.shape[1] - 1) // st_i + 1, (out.shape[2] - 1) // st_i + 1)
+        lazy_out = i + 1 < len(blocks) and _joins_on_load(blocks[i + 1], dtype, nshape) and _FUSE["max_cin"] == 0
         # (block recompute: this forward's activations are dropped and rebuilt, so it runs with the no-backward policy)
         ckpt = ckpt_on and stages[i] in _RECOMPUTE["layers"]
         out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out, pol_keep=keep and not ckpt)

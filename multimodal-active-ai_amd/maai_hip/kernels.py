@@ -279,6 +279,23 @@ def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=Non
     return int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
 
 
+def conv_module_family(conv, n, ih, iw, dtype):
+    """the same for an nn.Conv2d module on an [n, ih, iw, Cin] input of ``dtype`` (no tensors needed)"""
+    kh, kw = conv.kernel_size
+    s, p = conv.stride[0], conv.padding[0]
+    oh, ow = conv_out_hw(ih, iw, kh, kw, s, p, p)
+    d = ConvDesc(int(n), int(ih), int(iw), conv.in_channels, conv.out_channels, kh, kw, s, p, p, oh, ow, oh, ow, 1, 0, 0, 0)
+    return int(lib().maai_conv2d_kernel_family(C.byref(d), BF16 if dtype == torch.bfloat16 else F32))
+
+
+def conv2d_kernel_family(x, w, stride=1, pad_h=0, pad_w=0):
+    """0 ring / halo, 1 streaming, 2 ping-pong: the kernel a plain forward launch of this geometry gets (``x``: a tensor
+    or a Lazy — only its shape and dtype matter)."""
+    t = x.y if isinstance(x, Lazy) and x.y is not None else (x.b if isinstance(x, Lazy) else x)
+    d = make_desc(t, w, stride, pad_h, pad_w)
+    return int(lib().maai_conv2d_kernel_family(C.byref(d), _dt(t)))
+
+
 def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
                         grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False, axf=None,
                         sum_increment=False):
@@ -540,7 +557,9 @@ def bn_pack_stats(sums, count):
 def bn_finalize_gathered(gathered, gamma, beta, running_mean, running_var, momentum, eps):
     """``gathered``: [world, 2C+1] fp32 rows of ``bn_pack_stats`` (any row stride, unit column stride) -> what
     ``bn_finalize`` returns for the merged statistics (Chan's parallel variance in fp64)."""
-    _gpu(gathered)
+    _gpu(gamma, beta, running_mean, running_var)
+    if not gathered.is_cuda:
+        raise MaaiError("the HIP path needs tensors on a HIP device (got %s); there is no CPU fallback" % gathered.device)
     if gathered.dim() != 2 or gathered.dtype != torch.float32 or gathered.stride(1) != 1:
         raise MaaiError("bn_finalize_gathered: expected a [world, 2C+1] fp32 matrix with contiguous rows")
     world, c = gathered.shape[0], (gathered.shape[1] - 1) // 2

@@ -23,6 +23,12 @@ def short(name):
     return name
 
 
+FAMILIES = (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("conv_chain_kernel", "conv_igemm"), ("conv_bwd3_kernel", "conv_igemm"), ("conv_pp_kernel", "conv_igemm"), ("wgrad_pp_kernel", "conv_wgrad"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
+                 ("bn_act_fwd2_kernel", "bn_act_fwd"), ("bn_act_fwd_kernel", "bn_act_fwd"), ("bn_bwd_apply2_kernel", "bn_bwd_apply"),
+                 ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
+                 ("reduce_partials_kernel", "reduce_partials"))
+
+
 def biggest(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
@@ -30,8 +36,19 @@ def biggest(pattern):
     return max(files, key=os.path.getsize)
 
 
+def family(name):
+    """conv_igemm_kernel<bf16, 256, 128, 3, 6, false, true> -> conv_igemm (the names bench.py's table uses: every
+    convolution / data-gradient launch, ring or streaming kernel, is "conv_igemm"; every weight gradient "conv_wgrad")."""
+    base = name.split("<")[0]
+    for a, b in FAMILIES:
+        if base == a:
+            return b
+    return base
+
+
 def stats(src, out):
     f = biggest(os.path.join(src, "**", "*_kernel_stats.csv"))
+    fam = {}
     with open(f) as fh, open(out, "w", newline="") as oh:
         rd = csv.DictReader(fh)
         wr = csv.writer(oh)
@@ -39,6 +56,15 @@ def stats(src, out):
         for r in rd:
             wr.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], "%.1f" % float(r["AverageNs"]), r["Percentage"],
                          r["MinNs"], r["MaxNs"]])
+            e = fam.setdefault(family(short(r["Name"])), [0, 0.0])
+            e[0] += int(r["Calls"])
+            e[1] += float(r["TotalDurationNs"])
+        # the families bench.py's live table uses (every forward / data-gradient convolution launch is "conv_igemm",
+        # every weight gradient "conv_wgrad"): calls, total and average duration over all kernels of the family
+        wr.writerow([])
+        wr.writerow(["Family", "Calls", "TotalDurationNs", "AverageNs"])
+        for k, (n, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            wr.writerow(["family:" + k, n, "%.0f" % t, "%.1f" % (t / max(n, 1))])
     print("wrote", out, "from", f)
 
 
@@ -54,19 +80,6 @@ def per_kernel(src, counter):
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     return acc
-
-
-def family(name):
-    """conv_igemm_kernel<bf16, 256, 128, 3, 6, false, true> -> conv_igemm (the names bench.py's table uses: every
-    convolution / data-gradient launch, ring or streaming kernel, is "conv_igemm"; every weight gradient "conv_wgrad")."""
-    base = name.split("<")[0]
-    for a, b in (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("conv_chain_kernel", "conv_igemm"), ("conv_bwd3_kernel", "conv_igemm"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
-                 ("bn_act_fwd2_kernel", "bn_act_fwd"), ("bn_act_fwd_kernel", "bn_act_fwd"), ("bn_bwd_apply2_kernel", "bn_bwd_apply"),
-                 ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
-                 ("reduce_partials_kernel", "reduce_partials")):
-        if base == a:
-            return b
-    return base
 
 
 def pmc(fetch_dir, write_dir, out, command):

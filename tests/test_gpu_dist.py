@@ -87,7 +87,7 @@ def _worker(rank, world, port, q, backend="gloo", arch="resnet18"):
     torch.cuda.synchronize()
     engine.set_grad_hook(None)
     g_avg = {n: p.grad.clone() for n, p in m.named_parameters() if n in g_local}
-    stats = dict(D.STATS, launched_early=red.launched_early, nbuckets=len(red.buckets), hits_a=hits_a)
+    stats = dict(D.STATS, launched_early=red.launched_early, nbuckets=len(red.buckets), hits_a=hits_a, exchanges=dict(engine.EXCHANGES))
     q.put((rank, loss.item(), h2.detach().cpu().numpy(), logits.cpu().numpy(), labels.argmax(1).cpu().numpy(), rm,
            {n: v.cpu().numpy() for n, v in g_local.items()}, {n: v.cpu().numpy() for n, v in g_avg.items()}, stats))
     dist.destroy_process_group()
@@ -153,3 +153,8 @@ def _run_two_ranks(backend, port, arch="resnet18"):
         assert st["prefetch_started"] == 4 and st["prefetch_hits"] == 4 and st["hits_a"] == 2, st
         # the head's bucket(s) went out before the backbone was differentiated
         assert st["nbuckets"] >= 3 and st["launched_early"] >= 1 and st["buckets_early"] + st["buckets_late"] == st["nbuckets"], st
+        # SyncBatchNorm exchanges (fp32 mean | M2 | count gathers forward, fp32 sum all-reduces backward): one per
+        # BatchNorm layer, the two that meet at a projection shortcut sharing one — two steps of (no-grad forward,
+        # forward, backward) were run: the count DESIGN section 6 budgets latency for
+        per_pass = 17 if arch == "resnet18" else 49
+        assert st["exchanges"] == {"gather": 4 * per_pass, "reduce": 2 * per_pass}, st["exchanges"]
