@@ -234,29 +234,47 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     constexpr int INFL = (P == 0 || P == 3) ? 2 * NAI + NBI : NAI + 2 * NBI;
     constexpr int KIND = (P + 2) & 3;
     constexpr int BUF = (P < 2) ? (X ^ 1) : X;
+    bool do_issue = true;
     if constexpr (STEADY) {
       pp_wait_vm<INFL>();
-      issue_kind(std::integral_constant<int, KIND>(), BUF);
     } else {
       const int g = 4 * kt + P;
       if (g + 6 <= NE) pp_wait_vm<INFL>(); else tail_wait(g);
-      if (g + 6 < NE) issue_kind(std::integral_constant<int, KIND>(), BUF);
+      do_issue = g + 6 < NE;
     }
+#if !(MAAI_EXP & 4)
+    if (STEADY || do_issue) issue_kind(std::integral_constant<int, KIND>(), BUF);
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    auto mma_rows = [&](auto I0, auto I1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = decltype(I0)::value; i < decltype(I1)::value; ++i)
 #pragma unroll
-      for (int j = 0; j < TNQ; ++j)
+        for (int j = 0; j < TNQ; ++j)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if constexpr (NI == 0)
-            acc[MI * 4 + i][j] = Mma<T>::run(af[i][s], bf0[j][s], acc[MI * 4 + i][j]);
-          else
-            acc[MI * 4 + i][TNQ + j] = Mma<T>::run(af[i][s], bf1[j][s], acc[MI * 4 + i][TNQ + j]);
-        }
+          for (int s = 0; s < 2; ++s) {
+            if constexpr (NI == 0)
+              acc[MI * 4 + i][j] = Mma<T>::run(af[i][s], bf0[j][s], acc[MI * 4 + i][j]);
+            else
+              acc[MI * 4 + i][TNQ + j] = Mma<T>::run(af[i][s], bf1[j][s], acc[MI * 4 + i][TNQ + j]);
+          }
+    };
+    // (MAAI_EXP & 4, A/B build: this phase's LDS-DMA issued HERE, behind the first four MFMAs, instead of in the load
+    //  section ahead of the barrier.  Measured slower on every shape — 256->256 3x3 @56: 0.90 -> 0.99 ms, 512->512 @28: 0.76 ->
+    //  0.86, the step 317.8 -> 320.1 ms: the address arithmetic and the DMA issue delay the wave's own MFMA stream more
+    //  than they cost its partner from the load section.  The shipped kernel issues it in the load section.)
+#if !(MAAI_EXP & 4)
+    mma_rows(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+#else
+    mma_rows(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || do_issue) issue_kind(std::integral_constant<int, KIND>(), BUF);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rows(std::integral_constant<int, 1>(), std::integral_constant<int, 4>());
+#endif
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

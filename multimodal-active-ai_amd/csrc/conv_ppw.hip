@@ -9,6 +9,9 @@
 // ds_read_b64_tr_b16 (cdna_hip_programming.md T10; addressing as in conv_wgrad.hip's ring kernel).
 //   A_q[mi] = dy columns { wr*128 + mi*64 + r }  at position wr*64 + r        (wave rows: output channels)
 //   B_q[ni] = x  columns { wc*64 + ni*32 + c }   at position wc*32 + c        (wave columns: (tap, ci))
+#ifndef MAAI_EXP
+#define MAAI_EXP 0
+#endif
 #include "common.h"
 #include "maai_internal.h"
 #include "conv_ppw.h"
@@ -78,6 +81,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(PpwArgs a) {
   }
   // pixel state of this lane's two rows (tile 0): index, and for spatial layers (n, oh, ow) -> input origin offset
   int pm[2], pih[2], piw[2], poh[2], pow_[2], pbase[2];
+  const int row_step = a.stride * a.IW * a.Cin;          // input elements per output row
+  const int img_step = a.IH * a.IW * a.Cin;              // ... per image
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = ps + prow + 32 * i;
@@ -89,20 +94,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(PpwArgs a) {
     piw[i] = pow_[i] * a.stride - a.pad_w;
     pbase[i] = ((n * a.IH + pih[i]) * a.IW + piw[i]) * a.Cin;   // (host: the input has < 2^31 elements)
   }
+  // 64 pixels further, without a division: whole output rows first (64 = q*OW + rr, host-side constants), then the rest
+  const int adv_q = 64 / a.OW, adv_r = 64 - adv_q * a.OW;
   auto advance_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       pm[i] += 64;
       if (!dense) {
-        pow_[i] += 64;
-        while (pow_[i] >= a.OW) {
+        int dq = adv_q;
+        pow_[i] += adv_r;
+        if (pow_[i] >= a.OW) {
           pow_[i] -= a.OW;
-          if (++poh[i] == a.OH) poh[i] = 0;
+          ++dq;
         }
-        const int n = pm[i] / ohw;   // (cheap enough once per 64 MFMAs; keeps the image index exact)
+        poh[i] += dq;
+        int base = pbase[i] + dq * row_step + (pow_[i] * a.stride - a.pad_w - piw[i]) * a.Cin;
+        while (poh[i] >= a.OH) {   // into the next image (at most a few times: OH*OW >= 64 is not required)
+          poh[i] -= a.OH;
+          base += img_step - a.OH * row_step;
+        }
         pih[i] = poh[i] * a.stride - a.pad_h;
         piw[i] = pow_[i] * a.stride - a.pad_w;
-        pbase[i] = ((n * a.IH + pih[i]) * a.IW + piw[i]) * a.Cin;
+        pbase[i] = base;
       }
     }
   };
@@ -214,29 +227,44 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(PpwArgs a) {
     }
     constexpr int KIND = (P + 2) & 3;
     constexpr int BUF = (P < 2) ? (X ^ 1) : X;
+    bool do_issue = true;
     if constexpr (STEADY) {
       pw_wait_vm<6>();
-      issue_kind(std::integral_constant<int, KIND>(), BUF);
     } else {
       const int g = 4 * kt + P;
       if (g + 6 <= NE) pw_wait_vm<6>(); else tail_wait(g);
-      if (g + 6 < NE) issue_kind(std::integral_constant<int, KIND>(), BUF);
+      do_issue = g + 6 < NE;
     }
+#if !(MAAI_EXP & 4)
+    if (STEADY || do_issue) issue_kind(std::integral_constant<int, KIND>(), BUF);
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+    auto mma_rows = [&](auto I0, auto I1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = decltype(I0)::value; i < decltype(I1)::value; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if constexpr (NI == 0)
-            acc[MI * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], bf0[j][s], acc[MI * 4 + i][j], 0, 0, 0);
-          else
-            acc[MI * 4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], bf1[j][s], acc[MI * 4 + i][2 + j], 0, 0, 0);
-        }
+          for (int s = 0; s < 2; ++s) {
+            if constexpr (NI == 0)
+              acc[MI * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], bf0[j][s], acc[MI * 4 + i][j], 0, 0, 0);
+            else
+              acc[MI * 4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][s], bf1[j][s], acc[MI * 4 + i][2 + j], 0, 0, 0);
+          }
+    };
+    // (MAAI_EXP & 4: the A/B placement of conv_pp.hip, measured slower)
+#if !(MAAI_EXP & 4)
+    mma_rows(std::integral_constant<int, 0>(), std::integral_constant<int, 4>());
+#else
+    mma_rows(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || do_issue) issue_kind(std::integral_constant<int, KIND>(), BUF);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rows(std::integral_constant<int, 1>(), std::integral_constant<int, 4>());
+#endif
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();

@@ -877,7 +877,14 @@ extern "C" int maai_conv2d_wgrad_xf(const maai_conv_desc* d, const void* x, cons
       p.N = a.N; p.IH = a.IH; p.IW = a.IW; p.Cin = a.Cin; p.Cout = a.Cout; p.KH = a.KH; p.KW = a.KW;
       p.stride = a.stride; p.pad_h = a.pad_h; p.pad_w = a.pad_w; p.OH = a.OH; p.OW = a.OW;
       p.nCoB = p.nKB = 0; p.pix_per_split = 0;
-      if (maai_wgrad_pp_supported(p) && (mode == 2 || (a.Cin >= 256 && !getenv("MAAI_WGRAD_PATCH") && !getenv("MAAI_WGRAD_TILE"))))
+      // measured against the ring / patch kernels (scripts/ppw_ab.py, 256 images, interleaved): the pointwise layers gain
+      // 35-60 % (256->1024@56 0.69 -> 0.45 ms, 1024->512@56 1.18 -> 0.74, 512->2048@28 0.61 -> 0.40, strided shortcuts 0.38 ->
+      // 0.30); the 3x3 layers do not (256@56: 1.28 ms on the patch kernel vs 2.06; 512@28 and the strided ones tie) — their
+      // x operand is gathered per tap and pixel, which this kernel pays in address arithmetic
+      // (512-channel 3x3 layers, which the patch kernel's shape rule leaves to the ring kernel: 1.93 -> 1.68 ms at 28^2,
+      //  the stride-2 one at 56^2 2.04 -> 1.68)
+      const bool rule = (a.KH * a.KW == 1 && a.Cin >= 256) || (a.KH * a.KW == 9 && a.Cin >= 512);
+      if (maai_wgrad_pp_supported(p) && (mode == 2 || (rule && !getenv("MAAI_WGRAD_PATCH") && !getenv("MAAI_WGRAD_TILE"))))
         return maai_wgrad_pp_launch(p, st, target_blocks > 0 ? (target_blocks / 6 < 64 ? 64 : target_blocks / 6) : 0);
     }
   }

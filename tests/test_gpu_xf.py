@@ -20,6 +20,21 @@ def K():
     return kernels
 
 
+@pytest.fixture(autouse=True)
+def _ring_family():
+    """These cases compare the normalise-on-load launches with the materialised path ON THE SAME KERNEL FAMILY (ring /
+    halo / streaming): the statistics slab is compared bit for bit, and each family sums it in its own order.  The 8-wave
+    ping-pong kernel (conv_pp.hip) takes tensors only — the engine materialises a lazy input of a layer that runs on it
+    (engine._unit_fwd_gen), so a mixed pair never occurs in the product; tests/test_gpu_pp.py covers that kernel."""
+    old = os.environ.get("MAAI_CONV_PP")
+    os.environ["MAAI_CONV_PP"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("MAAI_CONV_PP", None)
+    else:
+        os.environ["MAAI_CONV_PP"] = old
+
+
 class env(object):
     def __init__(self, **kv):
         self.kv = kv
