@@ -304,6 +304,25 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
                               int normalize, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Comm helper: one-shot direct all-gather over the xGMI mesh (symmetric buffers, peer-to-peer stores) — the
+ * transport-level replacement of Objective._cross_replica_concat's dist.all_gather + torch.cat (SimCLR/Objective.py:
+ * 102-114) for the [B,128] embeddings; the RCCL path (torch.distributed) remains the default.  Setup: every rank
+ * creates its communicator (max_bytes = largest message, % 4 == 0), sends the 64-byte handle of its buffer to every peer
+ * by any means (the callers use their process group) and attaches the handles it receives.  maai_comm_allgather then
+ * writes this rank's message into its slot of every peer's buffer (8-byte {epoch, payload} granules, one system-scope
+ * store each: the data is the flag) and gathers dst[world][bytes] from its own buffer, all in one kernel on `stream`.
+ * A rank may run at most one gather ahead of any other rank (two epoch parities).  Spins are bounded; maai_comm_status
+ * returns the epoch of the first gather that gave up on a peer (0 = none; synchronises with the device).
+ * ------------------------------------------------------------------------ */
+typedef struct maai_comm maai_comm;
+int maai_comm_create(int rank, int world, long long max_bytes, maai_comm** out);
+int maai_comm_handle(maai_comm* c, void* handle64);
+int maai_comm_attach(maai_comm* c, int peer, const void* handle64);
+int maai_comm_allgather(maai_comm* c, const void* src, long long bytes, void* dst, void* stream);
+int maai_comm_status(maai_comm* c, unsigned* status);
+int maai_comm_destroy(maai_comm* c);
+
+/* ------------------------------------------------------------------------
  * Optimiser (Model_Util.py:68-88: torch.optim.Adam / SGD)
  * ------------------------------------------------------------------------ */
 int maai_adam_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,

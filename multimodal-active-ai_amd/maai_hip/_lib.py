@@ -84,6 +84,12 @@ SIGNATURES = {
     "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_d, c_d, c_d, c_d, c_i, c_f, c_p]),
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
     "maai_sgd_step_multi": (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
+    "maai_comm_create": (c_i, [c_i, c_i, c_ll, c_p]),
+    "maai_comm_handle": (c_i, [c_p, c_p]),
+    "maai_comm_attach": (c_i, [c_p, c_i, c_p]),
+    "maai_comm_allgather": (c_i, [c_p, c_p, c_ll, c_p, c_p]),
+    "maai_comm_status": (c_i, [c_p, c_p]),
+    "maai_comm_destroy": (c_i, [c_p]),
     "maai_multi_sqnorm": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "maai_larc_scale": (c_i, [c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
     "maai_softmax_ce_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

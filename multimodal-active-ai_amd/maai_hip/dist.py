@@ -74,7 +74,16 @@ def prefetch_embedding(h, normalize_fn, world_size=None, group=None):
         with torch.cuda.stream(side):
             z, inv = normalize_fn(hd.contiguous().float())
             out = torch.empty((world * z.shape[0], z.shape[1]), dtype=z.dtype, device=z.device)
-            work = dist.all_gather_into_tensor(out, z, group=group, async_op=True)
+            p2p = None
+            if z.is_cuda:
+                from . import comm
+                p2p = comm.p2p_gather_for(z.numel() * 4, group)   # MAAI_P2P_GATHER=1: one-shot direct all-gather over xGMI
+            if p2p is not None:
+                p2p.gather(z.contiguous(), out)
+                work = _Done()
+                STATS["p2p_gathers"] = STATS.get("p2p_gathers", 0) + 1
+            else:
+                work = dist.all_gather_into_tensor(out, z, group=group, async_op=True)
         hd.record_stream(side)
     else:
         z, inv = normalize_fn(hd.contiguous().float())
@@ -255,6 +264,13 @@ class GradReducer(object):
         for p in self.params:
             if id(p) in created:
                 p.grad = created[id(p)]
+
+
+class _Done(object):
+    """stands in for the Work handle of a collective that was enqueued as an ordinary kernel on the side stream"""
+
+    def wait(self):
+        return True
 
 
 class _Null(object):

@@ -42,10 +42,11 @@ def _inputs(B):
     return (torch.randint(0, 256, (B, 3, 32, 32), generator=g).float(), torch.randint(0, 256, (B, 3, 32, 32), generator=g).float())
 
 
-def _worker(rank, world, port, q, backend="gloo", arch="resnet18"):
+def _worker(rank, world, port, q, backend="gloo", arch="resnet18", p2p=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MAAI_P2P_GATHER"] = "1" if p2p else "0"
     if backend == "nccl":
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
@@ -112,11 +113,71 @@ def test_two_ranks_match_single_process(arch):
     _run_two_ranks("gloo", 29741 if arch == "resnet18" else 29745, arch)
 
 
-def _run_two_ranks(backend, port, arch="resnet18"):
+def test_two_ranks_direct_allgather_transport():
+    """The same step with the embedding gathers on the one-shot direct all-gather (csrc/comm.hip: symmetric buffers opened
+    across processes by IPC handle, peer-to-peer {epoch, payload} granule stores, MAAI_P2P_GATHER=1): same embeddings, loss,
+    labels and gradients; all four gathers of the two steps took the direct transport."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    _run_two_ranks("gloo", 29751, "resnet18", p2p=True)
+
+
+def _p2p_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _paths()
+    from maai_hip.comm import P2PGather
+    torch.cuda.set_device(0)
+    ok, detail = True, []
+    try:
+        pg = P2PGather(1 << 20)
+        for trial, b in enumerate([16, 512, 2048, 33, 512, 1, 2048, 512]):   # 8 KB .. 1 MB per rank, both epoch parities
+            g = torch.Generator().manual_seed(100 * trial + rank)
+            z = torch.randn(b, 128, generator=g).cuda()
+            out = pg.gather(z)
+            ref = torch.empty(world * b, 128, device="cuda")
+            dist.all_gather_into_tensor(ref, z)          # (also the flow control a real step provides between gathers)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(out, ref))
+            ok = ok and same
+            detail.append((b, same))
+        st = pg.status()
+        ok = ok and st == 0
+        # an integer payload goes through bit for bit too (the labels / counts some callers send)
+        zi = (torch.arange(64 * 4, device="cuda", dtype=torch.int32) * (rank + 3)).reshape(64, 4)
+        oi = pg.gather(zi)
+        torch.cuda.synchronize()
+        exp = torch.cat([(torch.arange(64 * 4, dtype=torch.int32) * (r + 3)).reshape(64, 4) for r in range(world)]).cuda()
+        ok = ok and bool(torch.equal(oi, exp))
+        pg.close()
+        q.put((rank, ok, detail, st))
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, False, repr(e), -1))
+    dist.destroy_process_group()
+
+
+def test_direct_allgather_matches_process_group_gather():
+    """csrc/comm.hip on its own: two processes on one MI355X, buffers exchanged by hipIpc handles, eight gathers of 0.5 KB to
+    1 MB per rank (alternating epoch parities) against torch.distributed's all_gather; no sweep gave up on a peer."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_p2p_worker, args=(r, 2, 29753, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=240) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    for r, ok, detail, st in res:
+        assert ok and st == 0, (r, detail, st)
+
+
+def _run_two_ranks(backend, port, arch="resnet18", p2p=False):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q, backend, arch)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, backend, arch, p2p)) for r in range(world)]
     [p.start() for p in ps]
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
@@ -158,3 +219,4 @@ def _run_two_ranks(backend, port, arch="resnet18"):
         # forward, backward) were run: the count DESIGN section 6 budgets latency for
         per_pass = 17 if arch == "resnet18" else 49
         assert st["exchanges"] == {"gather": 4 * per_pass, "reduce": 2 * per_pass}, st["exchanges"]
+        assert st.get("p2p_gathers", 0) == (4 if p2p else 0), st
