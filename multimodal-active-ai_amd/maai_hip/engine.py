@@ -861,7 +861,9 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
                 dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
                 grads[id(w)] = _grad_to_reference(rec, dw)
             dy.record_stream(side)                     # keep the allocator from recycling them early
-            rec.x.record_stream(side)
+            for t in ((rec.x.y, rec.x.b) if isinstance(rec.x, K.Lazy) else (rec.x,)):
+                if t is not None:
+                    t.record_stream(side)
             grads["_side"] = True
         else:
             dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
