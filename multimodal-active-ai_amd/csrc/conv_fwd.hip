@@ -182,6 +182,39 @@ static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
 // convolutions of stages 3-4 and their data gradients.  Its statistics slab has one row per 256 pixels — the row count
 // conv_plan already gives these shapes (256-row tiles), so selecting it changes no slab shape.
 // MAAI_CONV_PP = 0 (off) | 1 (shape rule, default) | 2 (every shape the kernel is built for), read per call.
+// The persistent resident-weights kernel (conv_c64.hip) takes the 64 -> 64 channel 3x3 stride-1 layers on large planes
+// (conv2 of layer 1's bottlenecks): forward with a tensor or a normalise-on-load input, and the data gradient whose mask
+// comes from the unit below's y*scale + shift.  One statistics-slab row per WAVE (6 per workgroup, one workgroup per CU).
+// MAAI_CONV_C64 = 0 (off) | 1 (shape rule, default) | 2 (every shape it is built for), read per call.
+static bool c64_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi, int dtype, const void* relu_mask) {
+  const char* e = getenv("MAAI_CONV_C64");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  if (mode == 1 && (getenv("MAAI_CONV_BM") || getenv("MAAI_CONV_BN") || getenv("MAAI_CONV_NSTAGE") || getenv("MAAI_CONV_HALO"))) return false;
+  if (dtype != MAAI_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad_h != 1 || d->pad_w != 1 || d->Cin != 64 || d->Cout != 64) return false;
+  if (d->OHg != d->IH || d->OWg != d->IW || d->OH != d->OHg || d->OW != d->OWg || d->out_stride != 1 || d->out_off_h || d->out_off_w) return false;
+  if (d->accumulate) return false;
+  const int emode = epi ? epi->mode : MAAI_EPI_STORE;
+  if (epi && (epi->xb || epi->a2 || epi->pre_x)) return false;
+  if (emode == MAAI_EPI_DGRAD_REDUCE) {
+    // (any mask form — none, tensor, 1-bit, or the unit below's y*scale + shift: the slab's row count is asked for without
+    //  knowing the mask, so the choice must not depend on it)
+    if (!epi->t || epi->xs) return false;
+  } else if (emode == MAAI_EPI_STORE) {
+    if (relu_mask) return false;   // (a masked store writes no slab)
+  } else {
+    return false;
+  }
+  if (mode == 2) return true;
+  const long long patches = (long long)d->N * ((d->IW + 15) / 16) * ((d->IH + 3) / 4);
+  return patches >= 8192 && d->IW % 16 == 0 && d->IH % 4 == 0;
+}
+static long long c64_rows(const maai_conv_desc* d) {
+  ConvArgs a;
+  a.N = d->N; a.IH = d->IH; a.IW = d->IW;
+  return maai_conv_c64_rows(a);
+}
+
 static bool pp_forced() {
   const char* e = getenv("MAAI_CONV_PP");
   return e && atoi(e) == 2;
@@ -319,6 +352,13 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   sel.dtype = dtype; sel.bm = plan.bm; sel.halo = plan.halo; sel.nstage = 3;
   sel.pw = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
   if (a.pre_x) return maai_conv_chain_launch(a, st);
+  if (c64_selected(d, epi, dtype, relu_mask)) {
+    if (!maai_conv_c64_supported(a, dtype)) {
+      maai_set_error("conv2d_igemm: internal: the 64-channel 3x3 kernel's shape rule and its support test disagree");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    return maai_conv_c64_launch(a, st);
+  }
   // (the default rule's shapes are never the streaming kernel's; MAAI_CONV_PP=2 — tests, A/B runs — takes every shape it can)
   if (pp_selected(d, epi, dtype, relu_mask) && (!pws || pp_forced())) {
     if (!maai_conv_pp_supported(a, dtype)) {
@@ -389,6 +429,7 @@ extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const
     return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
   const ConvPlan p = conv_plan(d, dtype);
   if (epi && epi->xs && p.bm == 64) return ((long long)d->N * d->OHg * d->OWg + 127) / 128;
+  if (c64_selected(d, epi, dtype, nullptr)) return c64_rows(d);
   // (the ping-pong kernel: one row per 256 pixels; a relu mask is unknown here — masked STORE launches write no slab)
   const bool pp = pp_selected(d, epi, dtype, nullptr);
   const long long pprows = maai_conv_pp_rows(d->Cout);
@@ -399,10 +440,12 @@ extern "C" long long maai_conv2d_stats_rows_fused(const maai_conv_desc* d, const
 }
 
 /* which kernel family a PLAIN forward launch (no epilogue descriptor, tensor input) of this geometry gets:
- * 0 = ring / halo (conv_igemm.h), 1 = streaming (conv_pws.hip), 2 = ping-pong (conv_pp.hip).  Each family sums the BatchNorm
+ * 0 = ring / halo (conv_igemm.h), 1 = streaming (conv_pws.hip), 2 = ping-pong (conv_pp.hip), 3 = persistent 64-channel 3x3
+ * (conv_c64.hip, which also takes normalise-on-load inputs).  Each family sums the BatchNorm
  * partial statistics in its own order; the engine keeps a layer on ONE family whatever form its input has. */
 extern "C" int maai_conv2d_kernel_family(const maai_conv_desc* d, int dtype) {
   if (!d) return 0;
+  if (c64_selected(d, nullptr, dtype, nullptr)) return 3;
   const bool pp = pp_selected(d, nullptr, dtype, nullptr);
   if (pp && pp_forced()) return 2;
   if (pws_selected(d, nullptr, dtype)) return 1;

@@ -877,4 +877,8 @@ int maai_conv_chain_launch(const ConvArgs& a, hipStream_t st);
 // conv_pp.hip: the 8-wave ping-pong kernel (256 x 256 tiles, 64-deep K-tiles) for the MFMA-bound layers
 bool maai_conv_pp_supported(const ConvArgs& a, int dtype);
 int maai_conv_pp_rows(int Cout);
+// conv_c64.hip: persistent resident-weights kernel for the 64 -> 64 channel 3x3 stride-1 layers (forward, lazy input, data gradient)
+bool maai_conv_c64_supported(const ConvArgs& a, int dtype);
+int maai_conv_c64_rows(const ConvArgs& a);
+int maai_conv_c64_launch(const ConvArgs& a, hipStream_t st);
 int maai_conv_pp_launch(const ConvArgs& a, hipStream_t st);

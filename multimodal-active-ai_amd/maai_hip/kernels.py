@@ -580,6 +580,11 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return scale, shift
 
 
+def _bn_name(base, m, c, tag):
+    """bench.py --detail: one table row per BatchNorm-pass shape"""
+    return base if not DETAIL[0] else "%s M%d C%d %s" % (base, m, c, tag)
+
+
 def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None, want_bits=False):
     """out = act(y*scale + shift (+ residual)); with ``want_bits`` (bf16) also the 1-bit ReLU mask of out
     (uint8 [numel/8]) -> (out, bits)."""
@@ -589,7 +594,7 @@ def bn_act_fwd(y, scale, shift, residual=None, relu=True, out=None, want_bits=Fa
     if out is None:
         out = torch.empty_like(y)
     bits = torch.empty((y.numel() // 8,), dtype=torch.uint8, device=y.device) if want_bits else None
-    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * (3 if residual is not None else 2) + (y.numel() // 8 if want_bits else 0)):
+    with _timed(_bn_name("bn_act_fwd", m, c, "res" if residual is not None else ""), 0.0, y.element_size() * y.numel() * (3 if residual is not None else 2) + (y.numel() // 8 if want_bits else 0)):
         check(lib().maai_bn_act_fwd_mask(_p(y), _p(scale), _p(shift), _p(residual), _p(out), _p(bits), m, c, 1 if relu else 0,
                                          _dt(y), _stream()), "maai_bn_act_fwd_mask")
     return (out, bits) if want_bits else out
@@ -604,7 +609,7 @@ def bn_act_fwd2(y, scale, shift, y2, scale2, shift2, relu=True, want_bits=False)
     m = y.numel() // c
     out = torch.empty_like(y)
     bits = torch.empty((y.numel() // 8,), dtype=torch.uint8, device=y.device) if want_bits else None
-    with _timed("bn_act_fwd", 0.0, y.element_size() * y.numel() * 3 + (y.numel() // 8 if want_bits else 0)):
+    with _timed(_bn_name("bn_act_fwd", m, c, "two"), 0.0, y.element_size() * y.numel() * 3 + (y.numel() // 8 if want_bits else 0)):
         check(lib().maai_bn_act_fwd2(_p(y), _p(scale), _p(shift), _p(y2), _p(scale2), _p(shift2), _p(out), _p(bits), m, c,
                                      1 if relu else 0, _dt(y), _stream()), "maai_bn_act_fwd2")
     return (out, bits) if want_bits else out
@@ -616,7 +621,7 @@ def bn_act_bwd_apply2(dz, y, k, y2, kb):
     c = dz.shape[-1]
     m = dz.numel() // c
     dy, dy2 = torch.empty_like(dz), torch.empty_like(dz)
-    with _timed("bn_bwd_apply", 0.0, dz.element_size() * dz.numel() * 5):
+    with _timed(_bn_name("bn_bwd_apply", m, c, "two"), 0.0, dz.element_size() * dz.numel() * 5):
         check(lib().maai_bn_act_bwd_apply2(_p(dz), _p(y), _p(k[0]), _p(k[1]), _p(k[2]), _p(y2), _p(kb[0]), _p(kb[1]), _p(kb[2]),
                                            _p(dy), _p(dy2), m, c, _dt(dz), _stream()), "maai_bn_act_bwd_apply2")
     return dy, dy2
@@ -632,7 +637,7 @@ def bn_act_bwd_reduce(dout, out, y, mean, relu):
     if y is None:
         part.zero_()
     nt = 1 + (1 if relu else 0) + (1 if y is not None else 0)
-    with _timed("bn_bwd_reduce", 0.0, dout.element_size() * dout.numel() * nt):
+    with _timed(_bn_name("bn_bwd_reduce", m, c, "t%d" % nt), 0.0, dout.element_size() * dout.numel() * nt):
         check(lib().maai_bn_act_bwd_reduce(_p(dout), _p(out), _p(y), _p(mean), _p(part), m, c, 1 if relu else 0, _dt(dout),
                                            _stream()), "maai_bn_act_bwd_reduce")
     return reduce_partials(part)
@@ -659,7 +664,7 @@ def bn_act_bwd_apply(dout, out, y, k1, k2, k3, relu, want_dy=True, want_dz=False
     dy = torch.empty_like(dout) if want_dy else None
     dz = torch.empty_like(dout) if want_dz else None
     nt = 1 + (1 if relu else 0) + (1 if k1 is not None else 0) + (1 if want_dy else 0) + (1 if want_dz else 0)
-    with _timed("bn_bwd_apply", 0.0, dout.element_size() * dout.numel() * nt):
+    with _timed(_bn_name("bn_bwd_apply", m, c, "t%d%s%s" % (nt, "+dy" if want_dy else "", "+dz" if want_dz else "")), 0.0, dout.element_size() * dout.numel() * nt):
         check(lib().maai_bn_act_bwd_apply(_p(dout), _p(out), _p(y), _p(k1), _p(k2), _p(k3), _p(dy), _p(dz), m, c,
                                           1 if relu else 0, _dt(dout), _stream()), "maai_bn_act_bwd_apply")
     return dy, dz

@@ -27,3 +27,15 @@ for flag in (1 << 40, 0, 250000, 1000000, 1 << 40, 0):   # rows up to which a un
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     print("eval forward, fused epilogues up to %d rows: %.1f ms  %.0f images/s" % (flag, dt * 1e3, B / dt), flush=True)
+
+if os.environ.get("DETAIL", "0") != "0":   # per-shape table of one eval forward at the default setting
+    from maai_hip import kernels as K
+    engine._EVAL_FUSE["max_rows"] = int(os.environ.get("MAAI_EVAL_FUSE_MAX_ROWS", "65536"))
+    K.DETAIL[0] = True
+    with torch.no_grad(), K.profile() as prof:
+        engine.backbone_fwd(f, x, dtype, keep=False)
+    K.DETAIL[0] = False
+    rows = sorted(prof.table().items(), key=lambda kv: -kv[1]["ms"])
+    print("total %.1f ms over %d launches" % (sum(v["ms"] for _, v in rows), sum(v["launches"] for _, v in rows)))
+    for k, v in rows:
+        print("%-72s n %2d %6.2f ms %5.0f TF/s %5.0f GB/s" % (k, v["launches"], v["ms"], v["flops"] / v["ms"] / 1e9, v["bytes"] / v["ms"] / 1e6))

@@ -1,0 +1,21 @@
+#!/bin/bash
+set -o pipefail
+OUT=gpurun_out/r3p
+mkdir -p $OUT
+export MAAI_WGRAD_TUNE_FILE=$PWD/$OUT/wgrad_tune.json
+timeout -k 10 300 python -m pytest tests/test_gpu_c64.py -x -q > $OUT/c64_tests.log 2>&1
+rc=$?; echo "c64 tests rc=$rc" | tee -a $OUT/summary.txt; tail -3 $OUT/c64_tests.log | cut -c1-300
+if [ $rc -ne 0 ]; then exit 1; fi
+timeout -k 10 900 python -m pytest tests -m gpu -q --maxfail 5 > $OUT/gpu_tests.log 2>&1
+rc=$?; echo "gpu tests rc=$rc" | tee -a $OUT/summary.txt; tail -8 $OUT/gpu_tests.log | cut -c1-300
+if [ $rc -ne 0 ]; then exit 1; fi
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c64.json 2> $OUT/bench_c64.err; echo "bench c64 rc=$?" | tee -a $OUT/summary.txt
+MAAI_CONV_C64=0 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_noc64.json 2> $OUT/bench_noc64.err; echo "bench noc64 rc=$?" | tee -a $OUT/summary.txt
+python3 -c "
+import json
+for n in ('bench_c64','bench_noc64'):
+    try:
+        d=json.load(open('$OUT/%s.json'%n)); print(n, d['value'], d['ms_per_step'], d['config']['loss'])
+    except Exception as e: print(n, 'ERR', e)
+" | tee -a $OUT/summary.txt
+DETAIL=1 timeout -k 10 300 python3 scripts/eval_bench.py > $OUT/eval_detail.txt 2>&1; echo "eval rc=$?" | tee -a $OUT/summary.txt

@@ -23,7 +23,7 @@ dur = []
 names = collections.Counter()
 for f in glob.glob(os.path.join(out, "p*", "**", "*_counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if not any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_pws", "conv_chain", "conv_pp", "conv_bwd3", "wgrad")):
+        if not any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_pws", "conv_chain", "conv_pp", "conv_c64", "conv_bwd3", "wgrad")):
             continue
         a = acc[r["Counter_Name"]]
         a[0] += 1

@@ -13,7 +13,7 @@ from maai_hip import kernels as K  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ROUNDS = 7
-ARMS = {"ring": {"MAAI_CONV_PP": "0"}, "pp": {"MAAI_CONV_PP": "2"}}
+ARMS = {"ring": {"MAAI_CONV_PP": "0", "MAAI_CONV_C64": "0"}, "pp": {"MAAI_CONV_PP": "2", "MAAI_CONV_C64": "1"}}
 
 
 def run(arm, fn):
@@ -37,7 +37,7 @@ def timeit(fn):
     return {k: (statistics.median(v), min(v)) for k, v in res.items()}
 
 
-def case(hw, cin, cout, k, stride=1, dgrad=False):
+def case(hw, cin, cout, k, stride=1, dgrad=False, lazy=False):
     n = B
     x = torch.randn(n, hw, hw, cin, device="cuda").bfloat16()
     w = (torch.randn(cout, k, k, cin, device="cuda") / (k * k * cin) ** 0.5).bfloat16()
@@ -54,6 +54,9 @@ def case(hw, cin, cout, k, stride=1, dgrad=False):
             slab = torch.empty(rows, 2, cout, device="cuda")
             K.conv2d_store_reduce(x, w, 1, pad, pad, out, slab, yb, mean, s, t, None)
             return out.clone(), slab
+    elif lazy:
+        xs, xt = torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.3
+        fn = lambda: K.conv2d(K.Lazy(x, xs, xt, True), w, stride, pad, pad, stats=True)
     else:
         fn = lambda: K.conv2d(x, w, stride, pad, pad, stats=True)
     y0, st0 = run("ring", fn)
@@ -84,6 +87,10 @@ if __name__ == "__main__":
         case(112, 256, 256, 3, stride=2)
         case(56, 512, 512, 3, stride=2)
         case(28, 1024, 2048, 1)
+    if which in ("all", "c64"):
+        case(224, 64, 64, 3)
+        case(224, 64, 64, 3, lazy=True)
+        case(224, 64, 64, 3, dgrad=True)
     if which in ("all", "c128", "new"):
         case(112, 128, 128, 3)
         case(112, 128, 128, 3, dgrad=True)

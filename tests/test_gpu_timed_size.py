@@ -95,7 +95,9 @@ def test_forward_conv_windows_and_statistics_at_224(K, layer):
                          ids=lambda l: l[0])
 def test_batch_split_invariance_at_256_images(K, layer):
     """conv(x) over 256 images == conv over 32-image slices, bit for bit (each output pixel depends on its own image
-    only), and so are the BatchNorm partial sums (same tiles, summed in fp64)."""
+    only), and so are the BatchNorm partial sums (same tiles, summed in fp64) — except on the persistent 64-channel
+    kernel (conv_c64.hip), whose waves carry their fp32 sums over all their patches: there the totals agree to fp32
+    summation order."""
     name, H, cin, cout, k, stride = layer
     N, S = 256, 32
     pad = k // 2
@@ -110,7 +112,10 @@ def test_batch_split_invariance_at_256_images(K, layer):
         acc += K.reduce_partials(ps)
         del ys, ps
     torch.cuda.synchronize()
-    np.testing.assert_allclose(acc.cpu().numpy(), total.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    if K.conv2d_kernel_family(x, w, stride, pad, pad) == 3:
+        np.testing.assert_allclose(acc.cpu().numpy(), total.cpu().numpy(), rtol=3e-5, atol=1e-3 * (N * H * H) ** 0.5)
+    else:
+        np.testing.assert_allclose(acc.cpu().numpy(), total.cpu().numpy(), rtol=1e-12, atol=1e-9)
     assert float(y[-1].float().abs().max()) > 0.1   # the tail of the tensor was written
 
 
