@@ -28,7 +28,7 @@ extern "C" {
 #define MAAI_BF16 0
 #define MAAI_F32 1
 
-#define MAAI_ABI_VERSION 4
+#define MAAI_ABI_VERSION 5
 
 int maai_abi_version(void);
 const char* maai_last_error(void);
@@ -67,9 +67,14 @@ int maai_conv2d_igemm(const maai_conv_desc* d, const void* x, const void* w, voi
                       const void* relu_mask, int dtype, void* stream);
 long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype);
 /* Kernel family of a plain forward launch of this geometry: 0 ring / halo, 1 streaming, 2 ping-pong (8 waves, 256 x 256
- * tiles).  The families sum the statistics slab in different orders (outputs are bit-identical); a caller that needs
+ * tiles), 3 persistent 64-channel 3x3.  The families sum the statistics slab in different orders (outputs are bit-identical); a caller that needs
  * bit-reproducible statistics across input forms keeps a layer on one family. */
 int maai_conv2d_kernel_family(const maai_conv_desc* d, int dtype);
+/* 1 if a MAAI_EPI_BN_ACT launch (inference with frozen statistics: out = act(conv*scale + shift (+ residual)), SimCLR.py's
+ * f in eval mode / the frozen backbone of SURVEY 8-f1, f4) of this geometry runs on the kernel its plain launch would use
+ * (streaming, ping-pong, halo, or the ring kernel's own 128-row tile); ``lazy`` != 0: with a normalise-on-load input (xs / xt:
+ * the streaming kernel only).  0: it would fall back to 128-row row-staged tiles — launch + BatchNorm pass is then faster. */
+int maai_conv2d_bn_act_fast(const maai_conv_desc* d, int dtype, int lazy);
 
 /* Fused epilogues for the HBM-bound pointwise layers: the GEMM is cheap next to its output traffic, so it is
  * run twice instead of materialising the raw conv output (resnet.py:109-110,130-133: conv3 -> bn3 -> += identity

@@ -23,6 +23,7 @@
 // the stride-2 data gradients), optional per-channel sum / sum-of-squares
 // partials for BatchNorm (one deterministic slab row per M-block, no atomics).
 #include "conv_igemm.h"
+#include <string.h>
 
 template <typename T, int BM, int BN, int NSTAGE, int EMODE>
 static int launch_conv_e(const ConvArgs& a, hipStream_t st) {
@@ -144,6 +145,7 @@ static ConvPlan conv_plan(const maai_conv_desc* d, int dtype) {
 template <int BN>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_conv_p<bf16_t, 256, BN, 3, 6, false, true>(a, st);
+  if (a.emode == MAAI_EPI_BN_ACT) return launch_conv_p<bf16_t, 256, BN, 3, 2, false, true>(a, st);
   if (a.emode != 0) {
     maai_set_error("conv2d_igemm: BN epilogues are for pointwise layers");
     return MAAI_ERR_UNSUPPORTED;
@@ -169,8 +171,9 @@ static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
   const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
   if (!(dtype == MAAI_BF16 && pw1 && d->Cout % 64 == 0)) return false;
   if (d->accumulate || d->out_stride != 1 || d->OH != d->OHg || d->OW != d->OWg) return false;
-  if (epi && ((epi->mode != MAAI_EPI_STORE && !(epi->mode == MAAI_EPI_STATS_ONLY && !epi->xb)) || epi->a2 || epi->pre_x)) return false;
+  if (epi && ((epi->mode != MAAI_EPI_STORE && !((epi->mode == MAAI_EPI_STATS_ONLY || epi->mode == MAAI_EPI_BN_ACT) && !epi->xb)) || epi->a2 || epi->pre_x)) return false;
   if (!(d->Cin == 64 || d->Cin == 128 || d->Cin == 256)) return false;
+  if (epi && epi->mode == MAAI_EPI_BN_ACT && d->Cout > 1024) return false;   // (its coefficient table lives in the statistics scratch)
   // ... and every forward launch with 256 input channels (conv1 of layer 1's blocks and of layer2.0: 1-7 % slower than the
   // ring kernel there): the chained launch of conv_chain.hip, which replaces the join-on-load form of those launches in
   // forwards without a backward pass, adds the statistics of ITS output in the streaming kernel's order, and plain, joined
@@ -231,6 +234,8 @@ static bool pp_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi, 
   if (epi && (epi->xs || epi->xb || epi->a2 || epi->pre_x)) return false;
   if (emode == MAAI_EPI_STORE) {
     if (d->accumulate || relu_mask) return false;
+  } else if (emode == MAAI_EPI_BN_ACT) {
+    if (d->accumulate || relu_mask || d->Cout % 256) return false;
   } else if (emode != MAAI_EPI_DGRAD_REDUCE) {
     return false;
   }
@@ -307,7 +312,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.pre_y_out = epi ? epi->pre_y_out : nullptr;
   const bool pws = pws_selected(d, epi, dtype);
   if (a.xs || a.xb) {
-    MAAI_CHECK_ARG(a.xs && a.xt && (emode == MAAI_EPI_STORE || (emode == MAAI_EPI_STATS_ONLY && pws)) && !d->accumulate && !relu_mask &&
+    MAAI_CHECK_ARG(a.xs && a.xt && (emode == MAAI_EPI_STORE || ((emode == MAAI_EPI_STATS_ONLY || (emode == MAAI_EPI_BN_ACT && !a.xb)) && pws)) && !d->accumulate && !relu_mask &&
                        d->out_stride == 1 && !a.a2,
                    "conv2d_igemm: the normalised-on-load operand needs xs and xt and a plain dense forward launch");
     const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
@@ -335,7 +340,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   ConvPlan plan = conv_plan(d, dtype);
-  if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY)) {  // 128-row, row-staged tiles only
+  if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY && !(emode == MAAI_EPI_BN_ACT && plan.halo))) {
+    // 128-row, row-staged tiles only (the frozen-BatchNorm epilogue also exists on the halo, streaming and ping-pong kernels)
     plan.bm = 128;
     plan.halo = false;
     plan.nMB = (a.M + 127) / 128;
@@ -450,6 +456,21 @@ extern "C" int maai_conv2d_kernel_family(const maai_conv_desc* d, int dtype) {
   if (pp && pp_forced()) return 2;
   if (pws_selected(d, nullptr, dtype)) return 1;
   return pp ? 2 : 0;
+}
+
+/* Does a MAAI_EPI_BN_ACT launch (frozen statistics) of this geometry run on the kernel its plain launch would use — the
+ * streaming, ping-pong or halo kernel, or the ring kernel's natural 128-row tile?  ``lazy``: with a normalise-on-load input
+ * (the streaming kernel only).  Otherwise it falls back to 128-row row-staged tiles, slower than launch + pass on large tensors. */
+extern "C" int maai_conv2d_bn_act_fast(const maai_conv_desc* d, int dtype, int lazy) {
+  if (!d) return 0;
+  maai_conv_epilogue e;
+  memset(&e, 0, sizeof(e));
+  e.mode = MAAI_EPI_BN_ACT;
+  if (pws_selected(d, &e, dtype)) return 1;
+  if (lazy) return 0;
+  if (pp_selected(d, &e, dtype, nullptr)) return 1;
+  const ConvPlan p = conv_plan(d, dtype);
+  return (p.halo || p.bm == 128) ? 1 : 0;
 }
 
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {

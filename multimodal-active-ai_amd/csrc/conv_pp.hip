@@ -372,6 +372,54 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
         a.stats[((long long)mb * 2 + which) * a.Cout + nb * BN + c] = t;
       }
     }
+  } else if constexpr (EMODE == 2) {
+    // MAAI_EPI_BN_ACT (frozen statistics): out = act(r(y)*scale + shift (+ residual)) on the bf16-rounded tile — the
+    // arithmetic of maai_bn_act_fwd on the stored tensor, so launch + pass and this launch give the same bits
+    float q0[8], q1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col0 + cch * 8 + e;
+      q0[e] = a.ep0 ? a.ep0[c] : 1.f;
+      q1[e] = a.ep1 ? a.ep1[c] : 0.f;
+    }
+    const T* __restrict__ res = reinterpret_cast<const T*>(a.et);
+    constexpr int NB = 4;
+#pragma unroll
+    for (int it0 = 0; it0 < 128 / RPI; it0 += NB) {
+      Vec16<T> vr[NB];
+      bool ok[NB];
+      long long off[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const long long m = row0 + (it0 + b) * RPI + crow;
+        ok[b] = full || m < a.M;
+        off[b] = m * a.Cout + col0 + cch * 8;
+        vr[b].zero();
+        if (ok[b] && res) vr[b].load(res + off[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!ok[b]) continue;
+        Vec16<T> v;
+        v.load(csrc + (it0 + b) * RPI * LDC);
+        float fv[8];
+        v.get(fv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fv[e] = fv[e] * q0[e] + q1[e];
+        if (res) {
+          float fr[8];
+          vr[b].get(fr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+        }
+        if (a.erelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] = fmaxf(fv[e], 0.f);
+        }
+        v.set(fv);
+        v.store(y + off[b]);
+      }
+    }
   } else {
     // data-gradient epilogue (EMODE 6 of conv_igemm.h): optional accumulate, mask (1-bit array, tensor, or the unit below's
     // y*scale + shift > 0), BatchNorm-backward partial sums of the STORED (rounded) gradient
@@ -494,7 +542,7 @@ static int launch_pp(ConvArgs a, hipStream_t st) {
 }
 
 // Shapes the kernel is built for: bf16, Cin % 64 == 0, K >= 128, <= 32 taps, Cout % 128 == 0, dense output grid, an input of
-// fewer than 2^31 elements, plain store (+ statistics) or the data-gradient epilogue.  Whether it is USED is the caller's
+// fewer than 2^31 elements, plain store (+ statistics), the data-gradient epilogue, or (256-channel tiles) the frozen-BatchNorm epilogue.  Whether it is USED is the caller's
 // shape rule (conv_fwd.hip).  Rows per tile (the statistics slab has one row per tile): 256, or 512 for Cout % 256 != 0.
 int maai_conv_pp_rows(int Cout) { return Cout % 256 == 0 ? 256 : 512; }
 
@@ -504,12 +552,14 @@ bool maai_conv_pp_supported(const ConvArgs& a, int dtype) {
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1ll << 31)) return false;
   if (a.xs || a.xb || a.a2 || a.pre_x) return false;
   if (a.emode == MAAI_EPI_STORE) return !a.accumulate && !a.mask;
+  if (a.emode == MAAI_EPI_BN_ACT) return a.Cout % 256 == 0 && !a.accumulate && !a.mask;   // (the 256 x 256 tile only)
   return a.emode == MAAI_EPI_DGRAD_REDUCE;
 }
 
 int maai_conv_pp_launch(const ConvArgs& a, hipStream_t st) {
   if (a.Cout % 256 == 0) {
     if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_pp<2, 4, 6>(a, st);
+    if (a.emode == MAAI_EPI_BN_ACT) return launch_pp<2, 4, 2>(a, st);
     return launch_pp<2, 4, 0>(a, st);
   }
   if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_pp<4, 2, 6>(a, st);

@@ -32,8 +32,12 @@ __device__ __forceinline__ void wait_vm() {
 // one read in step s-2.  That its reads are over is enforced, not left to instruction scheduling: every wave drains its
 // LDS reads (lgkmcnt(0), wait_vm above) before each barrier — the K loop is fully unrolled and hipcc does sink the MFMAs
 // of a step below the next barrier, which raced on a DIST + 1 ring before the drain existed; the spare slot is kept.
-// EMODE 0: plain store (+ statistics slab); 1: statistics slab only (the chained launch of conv_chain.hip recomputes the tensor).
-template <int KC, int BN, int DIST, int XF, int EMODE>
+// EMODE 0: plain store (+ statistics slab); 1: statistics slab only (the chained launch of conv_chain.hip recomputes the tensor);
+// 2: MAAI_EPI_BN_ACT — frozen statistics: out = act(r(y)*scale + shift (+ residual)) applied to the bf16-rounded tile on its
+// way out (the arithmetic of maai_bn_act_fwd on the stored tensor: bit-identical to launch + pass), no raw output in HBM.
+// RES (EMODE 2): a residual tensor is added; its tile is requested a whole column tile ahead (before the K loop), and the
+// loads enter the vmcnt bookkeeping next to the stores they follow.
+template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false>
 __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
   typedef bf16_t T;
   constexpr int TM = 2, BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
   constexpr int RPI = 64 / CPR;            // rows one wave-wide 16-byte access covers
   constexpr int NIT = 16 / RPI;            // such accesses per 16-row group
-  constexpr int NST = EMODE == 1 ? 0 : TM * NIT;   // global stores per wave per column tile
+  constexpr int NST = (EMODE == 1 ? 0 : TM * NIT) * (RES ? 2 : 1);   // global stores (+ residual loads) per wave per column tile
   constexpr int NSLOT = DIST + 2;
   constexpr int RING = NSLOT * STAGE;
   typedef Mma<T>::frag frag_t;
@@ -141,6 +145,29 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
     }
   }
 
+  // ---- EMODE 2: scale | shift of all output channels in LDS (the statistics scratch, unused here); residual prefetch ----
+  float* ecoef = red;
+  uint4 rv[(EMODE == 2 && RES) ? TM * NIT : 1];
+  auto load_res = [&](int ct) {   // the residual tile of column tile ct, in the epilogue's row-store layout
+    if constexpr (EMODE == 2 && RES) {
+      const T* __restrict__ res = reinterpret_cast<const T*>(a.et);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m0 = arow0 + i * 16 + lane / CPR;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const long long m = m0 + it * RPI;
+          rv[i * NIT + it] = make_uint4(0, 0, 0, 0);
+          if (full || m < a.M) rv[i * NIT + it] = ld16_nt(res + m * a.Cout + ct * BN + (lane % CPR) * 8);
+        }
+      }
+    }
+  };
+  if constexpr (EMODE == 2) {
+    for (int i = tid; i < 2 * a.Cout; i += 256) ecoef[i] = i < a.Cout ? (a.ep0 ? a.ep0[i] : 1.f) : (a.ep1 ? a.ep1[i - a.Cout] : 0.f);
+    load_res(0);   // (issued before any weight stage: older than everything the K loop waits for)
+  }
+
   // ---- weight stages: stage s = (column tile s / KT, K-step s % KT), 64-byte rows, swizzled like conv_igemm ----
   const int r0 = tid >> 2;
   const int chunk = (tid & 3) ^ (((r0 >> 3) & 1) << 1);
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   float* sred = red + ((widu * 4 + (lane >> 4)) * 2) * BN + (lane & 15);
 
   auto finish_stats = [&](int ct) {  // after a barrier that follows the epilogue of column tile ct
-    if (a.stats && EMODE != 6) {
+    if (a.stats && EMODE != 6 && EMODE != 2) {
 #pragma unroll
       for (int o = tid; o < 2 * BN; o += 256) {
         const int which = o / BN, c = o - which * BN;
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
     }
 
     // ---- epilogue of column tile ct: wave-private, no workgroup barrier ----
-    if (a.stats && EMODE != 6) {
+    if (a.stats && EMODE != 6 && EMODE != 2) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -260,12 +287,50 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
       const long long m0 = arow0 + i * 16 + lane / CPR;
       T* dst = y + m0 * a.Cout + ct * BN + (lane % CPR) * 8;
       const T* csrc = reinterpret_cast<const T*>(cw) + (lane / CPR) * LDC + (lane % CPR) * 8;
+      if constexpr (EMODE == 2) {
+        float q0[8], q1[8];
+        {
+          const float* cs = ecoef + ct * BN + (lane % CPR) * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            q0[e] = cs[e];
+            q1[e] = cs[a.Cout + e];
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          Vec16<T> v;
+          v.load(csrc + it * RPI * LDC);
+          float fv[8];
+          v.get(fv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] = fv[e] * q0[e] + q1[e];
+          if constexpr (RES) {
+            Vec16<T> r;
+            r.raw = rv[i * NIT + it];
+            float fr[8];
+            r.get(fr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+          }
+          if (a.erelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] = fmaxf(fv[e], 0.f);
+          }
+          v.set(fv);
+          if (full || m0 + it * RPI < a.M) v.store(dst + (long long)it * RPI * a.Cout);
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         Vec16<T> v;
         v.load(csrc + it * RPI * LDC);
         if (full || m0 + it * RPI < a.M) v.store(dst + (long long)it * RPI * a.Cout);
       }
+      }
+    }
+    if constexpr (EMODE == 2 && RES) {
+      if (ct + 1 < nCT) load_res(ct + 1);   // behind this tile's stores: one package of NST vector-memory operations per epilogue
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -273,14 +338,14 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   finish_stats(nCT - 1);
 }
 
-template <int KC, int BN, int DIST, int XF, int EMODE>
+template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false>
 static int launch_pws(ConvArgs a, hipStream_t st) {
   constexpr int lds = (DIST + 2) * BN * 64 + 4 * 16 * (BN + 8) * 2 + 32 * BN * 4;
   static_assert(4 * KC * 4 <= 4 * 16 * (BN + 8) * 2, "the coefficient table borrows the C area");
   a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
-  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE>), lds, attr_lds);
-  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), lds, attr_lds);
+  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -294,6 +359,20 @@ static int pws_k(const ConvArgs& a, hipStream_t st) {
       return MAAI_ERR_UNSUPPORTED;
     }
     return a.xs ? launch_pws<KC, BN, DIST, 1, 1>(a, st) : launch_pws<KC, BN, DIST, 0, 1>(a, st);
+  }
+  if (a.emode == MAAI_EPI_BN_ACT) {
+    if (a.xb) {
+      maai_set_error("conv2d_igemm: the BatchNorm epilogue of the streaming kernel takes a plain or normalised-on-load input");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    if (a.Cout > 16 * BN) {
+      maai_set_error("conv2d_igemm: the streaming kernel's BatchNorm epilogue keeps scale | shift in LDS: Cout <= 16 column tiles");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    ConvArgs b = a;
+    b.stats = nullptr;   // (the statistics scratch holds the coefficient table)
+    if (a.et) return a.xs ? launch_pws<KC, BN, DIST, 1, 2, true>(b, st) : launch_pws<KC, BN, DIST, 0, 2, true>(b, st);
+    return a.xs ? launch_pws<KC, BN, DIST, 1, 2, false>(b, st) : launch_pws<KC, BN, DIST, 0, 2, false>(b, st);
   }
   if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
   if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
     "maai_conv2d_kernel_family": (c_i, [_P_DESC, c_i]),
+    "maai_conv2d_bn_act_fast": (c_i, [_P_DESC, c_i, c_i]),
     "maai_conv2d_stats_rows_fused": (c_ll, [_P_DESC, _P_EPI, c_i]),
     "maai_conv2d_igemm_fused": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, _P_EPI, c_i, c_p]),
     "maai_conv_bwd3_rows": (c_i, [c_ll]),
@@ -106,7 +107,7 @@ class MaaiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
+ABI_VERSION = 5   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
 
 
 def _autobuild():

@@ -239,6 +239,11 @@ def _fusable(conv, form, keep=True):
             and conv.in_channels <= lim and conv.out_channels >= 4 * conv.in_channels)
 
 
+def _bn_training(bn):
+    """does this norm layer take batch statistics in this forward?  (unit_fwd's rule)"""
+    return False if _is_frozen_bn(bn) else bool(bn.training or (bn.running_mean is None))
+
+
 def _is_frozen_bn(bn):
     return (not isinstance(bn, torch.nn.modules.batchnorm._BatchNorm)
             and all(hasattr(bn, a) for a in ("weight", "bias", "running_mean", "running_var")))
@@ -265,7 +270,12 @@ _DUAL_BN = {"enabled": os.environ.get("MAAI_DUAL_BN", "1") != "0"}
 # Inference with frozen statistics: conv + BN (+ shortcut) + ReLU in ONE launch per unit (MAAI_EPI_BN_ACT) where the tensors
 # are small enough for launch count to matter; on large ones the lazy / streaming / chained path of the training forward
 # (minus its statistics) is faster (ResNet-50, 224^2 x 256: 79.6 vs 67.8 ms).  max_rows: output pixels up to which a unit fuses.
-_EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0", "max_rows": int(os.environ.get("MAAI_EVAL_FUSE_MAX_ROWS", "65536"))}
+# "fast" (round 3): beyond max_rows a unit still fuses where the epilogue runs on the kernel the plain launch would use
+# (streaming, ping-pong, halo, the ring kernel's own 128-row tile: kernels.conv_bn_act_fast) AND its activation would
+# otherwise be written by a BatchNorm pass — i.e. not where the consumer forms it on load for free or the block boundary
+# is chained (layer 1).  ResNet-50, 224^2 x 256: 63.3 -> see DESIGN section 5.  MAAI_EVAL_FUSE_FAST=0 turns the rule off.
+_EVAL_FUSE = {"enabled": os.environ.get("MAAI_EVAL_FUSE", "1") != "0", "max_rows": int(os.environ.get("MAAI_EVAL_FUSE_MAX_ROWS", "65536")),
+              "fast": os.environ.get("MAAI_EVAL_FUSE_FAST", "1") != "0"}
 # Normalise-on-load (kernels.Lazy): a unit whose only consumers are convolutions of this library does not run its
 # BatchNorm/ReLU pass; it hands on its RAW convolution output with (scale, shift) and the consumers (forward
 # convolution, weight gradient) apply the transform to the operand they stage in LDS.  "lazy": inside a block
@@ -299,6 +309,21 @@ def set_chain(enabled):
     """Chained block boundaries in forwards without a backward pass (default on; MAAI_CHAIN=0).  Everything the chained
     launch writes — output, joined activation, mask, statistics slab — is bit-identical to the launches it replaces."""
     _CHAIN["enabled"] = bool(enabled)
+
+
+def _eval_unit_fast(conv, x, dtype):
+    """Inference with frozen statistics: does conv + BN (+ shortcut) + ReLU in one launch run at the plain launch's speed for
+    this unit (``x``: its input, a tensor or a Lazy)?  A lazy input must be a single tensor the streaming kernel can form."""
+    if not _EVAL_FUSE["fast"] or dtype != torch.bfloat16:
+        return False
+    lazy = isinstance(x, K.Lazy)
+    if lazy and (x.b is not None or x.pre is not None):
+        return False
+    env = os.environ   # (a forced ring-kernel tile — the parity tests sweep those knobs — is not what the rule was measured on)
+    if any(k in env for k in ("MAAI_CONV_BM", "MAAI_CONV_BN", "MAAI_CONV_NSTAGE")):
+        return False
+    n, h, w = x.shape[0], x.shape[1], x.shape[2]
+    return K.conv_bn_act_fast(conv, n, h, w, dtype, lazy=lazy)
 
 
 def _chain_ok(conv, x, dtype):
@@ -519,11 +544,17 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     pad_w = pad if kw > 1 else 0
     fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
     rows_out = (x.shape[0] * ((x.shape[1] + 2 * pad - kh) // stride + 1) * ((x.shape[2] + 2 * pad_w - kw) // stride + 1))
-    eval_fused = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
-                  and wq.shape[0] % 64 == 0 and rows_out <= _EVAL_FUSE["max_rows"])
+    eval_ok = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
+               and wq.shape[0] % 64 == 0)
+    eval_fused = eval_ok and rows_out <= _EVAL_FUSE["max_rows"]
+    eval_lazy = False    # the fused launch also forms its (single-tensor) lazy input on load
+    if (eval_ok and not eval_fused and form == "fwd" and _eval_unit_fast(conv, x, dtype)
+            and not (lazy_out and (residual is None or _chain_ok(conv, x, dtype)))):
+        eval_fused = True
+        eval_lazy = isinstance(x, K.Lazy)
     # (a layer stays on ONE kernel family whatever form its input has: the families sum the statistics slab in different
     #  orders, and the ping-pong kernel of conv_pp.hip takes tensors only — a lazy input to one of its layers is materialised)
-    if isinstance(x, K.Lazy) and (fused or eval_fused or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
+    if isinstance(x, K.Lazy) and (fused or (eval_fused and not eval_lazy) or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
                                   or K.conv_module_family(conv, x.shape[0], x.shape[1], x.shape[2], dtype) == 2):
         x = materialise(x)
         if side is not None:
@@ -980,7 +1011,14 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
         r2 = None
         last_conv, last_bn = blk.conv2, blk.bn2
     rd = None
-    if blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd"):
+    dual = blk.downsample is not None and _DUAL_BN["enabled"] and not _fusable(blk.downsample[0], "fwd") and not _fusable(last_conv, "fwd")
+    if (dual and not keep and given is None and _EVAL_FUSE["enabled"] and not _bn_training(blk.downsample[1]) and not _bn_training(last_bn)
+            and _eval_unit_fast(blk.downsample[0], xin, dtype) and _eval_unit_fast(last_conv, o, dtype)
+            and not (lazy_out and _chain_ok(last_conv, o, dtype))):
+        # frozen statistics: both branches normalise in their own epilogues, the second one adds the first (not where the
+        # block boundary is chained: that launch normalises the projection shortcut on load)
+        dual = False
+    if dual:
         # the shortcut's BatchNorm is applied inside the last unit's pass: its normalised map is never stored; with
         # SyncBatchNorm the two units' statistics travel in ONE all-reduce (_drive_pair)
         box = [None]

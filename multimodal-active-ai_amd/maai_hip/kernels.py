@@ -289,7 +289,7 @@ def conv_module_family(conv, n, ih, iw, dtype):
 
 
 def conv2d_kernel_family(x, w, stride=1, pad_h=0, pad_w=0):
-    """0 ring / halo, 1 streaming, 2 ping-pong: the kernel a plain forward launch of this geometry gets (``x``: a tensor
+    """0 ring / halo, 1 streaming, 2 ping-pong, 3 persistent 64-channel 3x3: the kernel a plain forward launch of this geometry gets (``x``: a tensor
     or a Lazy — only its shape and dtype matter)."""
     t = x.y if isinstance(x, Lazy) and x.y is not None else (x.b if isinstance(x, Lazy) else x)
     d = make_desc(t, w, stride, pad_h, pad_w)
@@ -416,12 +416,43 @@ def conv2d_chained(xf, w, stats=False, join_bits=False, keep_y=False):
 
 
 def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=0, pad_w=0):
-    """out = act(conv(x, w)*scale + shift (+ residual)) in the conv epilogue (pass 2 of the fused unit)."""
+    """out = act(conv(x, w)*scale + shift (+ residual)) in the conv epilogue (pass 2 of the fused unit; every unit of an
+    inference forward with frozen statistics).  ``x`` may be a single-tensor ``Lazy`` where the streaming kernel takes the
+    shape (``conv_bn_act_fast(..., lazy=True)``): formed on load AND normalised on store in one launch."""
+    if isinstance(x, Lazy):
+        if x.b is not None or x.pre is not None:
+            raise MaaiError("conv2d_bn_act: a single-tensor Lazy")
+        xt = x.y
+        _gpu(xt, w, scale, shift, residual)
+        d = make_desc(xt, w, stride, pad_h, pad_w)
+        epi = _xf_epilogue(x)
+        epi.mode, epi.relu = EPI_BN_ACT, 1 if relu else 0
+        epi.p0, epi.p1, epi.t = scale.data_ptr(), shift.data_ptr(), (None if residual is None else residual.data_ptr())
+        out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=xt.dtype, device=xt.device)
+        m = d.N * d.OHg * d.OWg
+        es = xt.element_size()
+        nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[xf1 epi2] M%d Cin%d Cout%d k%dx%d" % (m, d.Cin, d.Cout, d.KH, d.KW)
+        with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
+                    es * (xt.numel() + w.numel() + m * d.Cout * (2 if residual is not None else 1)), es * (xt.numel() + m * d.Cout)):
+            check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(xt), _p(w), _p(out), None, None, C.byref(epi), _dt(xt), _stream()),
+                  "maai_conv2d_igemm_fused")
+        return out
     _gpu(x, w, scale, shift, residual)
     d = make_desc(x, w, stride, pad_h, pad_w)
     out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
     _conv_fused(x, w, stride, pad_h, pad_w, EPI_BN_ACT, out, None, scale, shift, None, residual, relu)
     return out
+
+
+def conv_bn_act_fast(conv, n, ih, iw, dtype, lazy=False):
+    """Does the frozen-BatchNorm epilogue of this nn.Conv2d on an [n, ih, iw, Cin] input run on the kernel its plain launch
+    would use (maai_conv2d_bn_act_fast)?  ``lazy``: with a normalise-on-load input."""
+    kh, kw = conv.kernel_size
+    s, p = conv.stride[0], conv.padding[0]
+    pw = p if kw > 1 else 0
+    oh, ow = conv_out_hw(ih, iw, kh, kw, s, p, pw)
+    d = ConvDesc(int(n), int(ih), int(iw), conv.in_channels, conv.out_channels, kh, kw, s, p, pw, oh, ow, oh, ow, 1, 0, 0, 0)
+    return bool(lib().maai_conv2d_bn_act_fast(C.byref(d), BF16 if dtype == torch.bfloat16 else F32, 1 if lazy else 0))
 
 
 def conv2d_bwd_reduce(x, w, dz, mean, stride=1, pad_h=0, pad_w=0):

@@ -14,8 +14,10 @@ f.train()
 with torch.no_grad():
     engine.backbone_fwd(f, x, dtype, keep=False)
 f.eval()
-for flag in (1 << 40, 0, 250000, 1000000, 1 << 40, 0):   # rows up to which a unit uses the fused epilogue
+for fast, flag in ((False, 1 << 40), (False, 0), (True, 0), (True, 65536), (False, 0), (True, 65536)):
+    # fast: units beyond ``flag`` rows still fuse where the epilogue runs on the plain launch's kernel (engine._EVAL_FUSE)
     engine._EVAL_FUSE["max_rows"] = flag
+    engine._EVAL_FUSE["fast"] = fast
     with torch.no_grad():
         for _ in range(2):
             engine.backbone_fwd(f, x, dtype, keep=False)
@@ -26,11 +28,12 @@ for flag in (1 << 40, 0, 250000, 1000000, 1 << 40, 0):   # rows up to which a un
             engine.backbone_fwd(f, x, dtype, keep=False)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("eval forward, fused epilogues up to %d rows: %.1f ms  %.0f images/s" % (flag, dt * 1e3, B / dt), flush=True)
+    print("eval forward, fused epilogues up to %d rows%s: %.1f ms  %.0f images/s" % (flag, " + fast-kernel rule" if fast else "", dt * 1e3, B / dt), flush=True)
 
 if os.environ.get("DETAIL", "0") != "0":   # per-shape table of one eval forward at the default setting
     from maai_hip import kernels as K
     engine._EVAL_FUSE["max_rows"] = int(os.environ.get("MAAI_EVAL_FUSE_MAX_ROWS", "65536"))
+    engine._EVAL_FUSE["fast"] = os.environ.get("MAAI_EVAL_FUSE_FAST", "1") != "0"
     K.DETAIL[0] = True
     with torch.no_grad(), K.profile() as prof:
         engine.backbone_fwd(f, x, dtype, keep=False)
