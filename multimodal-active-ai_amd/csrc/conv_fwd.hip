@@ -55,6 +55,9 @@ static int launch_conv_n(const ConvArgs& a, hipStream_t st) {
     }
   }
   if (a.emode == MAAI_EPI_DGRAD_REDUCE) return launch_conv_e<T, BM, BN, NSTAGE, 6>(a, st);
+  if constexpr (BM == 256 && sizeof(T) == 2) {   // the frozen-BatchNorm epilogue also on the channel-reducing pointwise layers' 256-row tile
+    if (a.emode == MAAI_EPI_BN_ACT) return launch_conv_e<T, BM, BN, NSTAGE, 2>(a, st);
+  }
   if (a.emode != 0) {
     maai_set_error("conv2d_igemm: fused epilogues need the 128-row tile");
     return MAAI_ERR_UNSUPPORTED;
@@ -340,7 +343,9 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   MAAI_CHECK_ARG(a.M < (1ll << 31), "conv2d_igemm: pixel count must fit 31 bits");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   ConvPlan plan = conv_plan(d, dtype);
-  if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY && !(emode == MAAI_EPI_BN_ACT && plan.halo))) {
+  const bool pw1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+  if (axf || (emode >= MAAI_EPI_STATS_ONLY && emode <= MAAI_EPI_BWD_APPLY &&
+              !(emode == MAAI_EPI_BN_ACT && (plan.halo || (plan.bm == 256 && pw1x1 && dtype == MAAI_BF16))))) {
     // 128-row, row-staged tiles only (the frozen-BatchNorm epilogue also exists on the halo, streaming and ping-pong kernels)
     plan.bm = 128;
     plan.halo = false;
@@ -398,8 +403,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     const char* e = getenv("MAAI_CONV_BN");
     const int fbn = e ? atoi(e) : 0;
     if (!axf && dtype == MAAI_BF16 && bm == 128 && d->KH * d->KW == 1 && d->Cout % 256 == 0 && fbn != 128 && fbn != 64 &&
-        (emode == MAAI_EPI_STORE || emode == MAAI_EPI_DGRAD_REDUCE) &&
-        (fbn == 256 || (emode == MAAI_EPI_STORE && !d->accumulate && !relu_mask && d->Cout >= 2 * d->Cin && d->Cin >= 256 &&
+        (emode == MAAI_EPI_STORE || emode == MAAI_EPI_DGRAD_REDUCE || emode == MAAI_EPI_BN_ACT) &&
+        (fbn == 256 || ((emode == MAAI_EPI_STORE || emode == MAAI_EPI_BN_ACT) && !d->accumulate && !relu_mask && d->Cout >= 2 * d->Cin && d->Cin >= 256 &&
                         a.nMB * (long long)(d->Cout / 256) >= 512))) {
       // measured in bench.py (B = 256, per launch): 256->1024 0.78 -> 0.74 ms, 512->2048 0.59 -> 0.56, 1024->2048/s2
       // 1.09 -> 0.96; the read-modify-write epilogues (3.3 -> 4.1 ms on 128->512 with accumulate + sums) and K <= 128
@@ -470,7 +475,8 @@ extern "C" int maai_conv2d_bn_act_fast(const maai_conv_desc* d, int dtype, int l
   if (lazy) return 0;
   if (pp_selected(d, &e, dtype, nullptr)) return 1;
   const ConvPlan p = conv_plan(d, dtype);
-  return (p.halo || p.bm == 128) ? 1 : 0;
+  const bool pw1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+  return (p.halo || p.bm == 128 || (p.bm == 256 && pw1x1 && dtype == MAAI_BF16)) ? 1 : 0;
 }
 
 extern "C" long long maai_conv2d_stats_rows(const maai_conv_desc* d, int dtype) {

@@ -51,6 +51,8 @@ CASES = [
     ("halo 3x3 128", dict(MAAI_CONV_HALO="1", MAAI_CONV_PP="0"), (2, 30, 32, 128, 128, 3, 1), False),
     ("halo 3x3 64", dict(MAAI_CONV_HALO="1", MAAI_CONV_C64="0"), (2, 33, 20, 64, 64, 3, 1), False),
     ("ring 128-row 512->2048", dict(MAAI_CONV_PP="0"), (2, 7, 7, 512, 2048, 1, 1), False),
+    ("ring 128 x 256 tile 512->2048", dict(MAAI_CONV_PP="0", MAAI_CONV_BN="256"), (3, 9, 9, 512, 2048, 1, 1), False),
+    ("ring 256-row 512->128", dict(MAAI_CONV_PP="0", MAAI_CONV_BM="256"), (3, 20, 21, 512, 128, 1, 1), False),
 ]
 
 
@@ -93,8 +95,8 @@ def test_fast_rule(K):
     assert K.conv_bn_act_fast(c, 256, 56, 56, bf) and not K.conv_bn_act_fast(c, 256, 56, 56, bf, lazy=True)   # ping-pong: tensors only
     c = nn.Conv2d(128, 128, 3, padding=1, bias=False)
     assert K.conv_bn_act_fast(c, 256, 112, 112, bf)    # halo
-    c = nn.Conv2d(512, 128, 1, bias=False)              # channel-reducing ring layer on 256-row tiles: launch + pass
-    assert not K.conv_bn_act_fast(c, 256, 112, 112, bf)
+    c = nn.Conv2d(512, 128, 1, bias=False)              # channel-reducing ring layer on 256-row tiles
+    assert K.conv_bn_act_fast(c, 256, 112, 112, bf)
 
 
 def test_eval_forward_with_fast_rule_equals_pass_path():
