@@ -7,32 +7,39 @@
 // conv_igemm.h — 18 barrier-separated K-steps per 256-row tile, two workgroups per CU, prologue and epilogue exposed —
 // runs them at 1.36 / 1.79 / 1.99 ms inside the step.  Here:
 //   * the weights (64 x 9 x 64 bf16 = 72 KB) stay in LDS for the whole launch;
-//   * one persistent workgroup of six waves per CU; every WAVE owns its own stream of 16 x 4-pixel output patches and its
-//     own 18 x 6-pixel halo image in LDS (13.5 KB): no workgroup barrier after the weights are in;
-//   * the next patch's halo is loaded into REGISTERS (14 x 16 bytes per lane: twelve 1 KB-contiguous row segments from a
-//     scalar base + lane offset, two edge-column loads) before the current patch's 288 MFMAs and written to LDS at the top
-//     of the next iteration;
+//   * one persistent workgroup of FOUR waves per CU — one per SIMD, up to 512 registers each; every WAVE owns its own stream
+//     of 16 x 7-pixel output patches (16 x 6 in the data gradient) and its own 18 x 9-pixel halo image in LDS (20 KB): no
+//     workgroup barrier after the weights are in, no SIMD carries more waves than another (a first version had six waves of
+//     16 x 4 patches, all that LDS admits at 256 registers: two SIMDs carried two waves, two carried one — 0.99 / 1.20 / 1.85 ms);
+//   * the next patch's halo is loaded into REGISTERS (21 x 16 bytes per lane: row segments of 1 KB, two edge columns)
+//     before the current patch's 504 MFMAs and written to LDS at the top of the next iteration;
 //   * the weights are the MFMA's A operand, permuted so that one lane ends up with EIGHT CONSECUTIVE output channels of a
-//     pixel: the epilogue is 16-byte row stores straight from the accumulators — no LDS transpose (the first version
+//     pixel: the epilogue is 16-byte row stores straight from the accumulators — no LDS transpose (the very first version
 //     had one: 256 ds_write_b16 per patch, 1.22 ms);
+//   * the packed output rows are stored one iteration LATE, in front of the request for the halo after next: issued right
+//     after the MFMAs they are younger than the halo loads in flight, and the waits hipcc derives for the LDS refill (it
+//     counts the loads only) then run down to vmcnt(0) — every refill waited for the previous patch's stores to be
+//     acknowledged (data gradient 2.16 -> 2.00 ms);
 //   * fragments are double-buffered by hand (the reads of K-step k + 1 are issued before the MFMAs of step k);
 //   * normalise-on-load (XF): applied once per halo element on the way from the prefetch registers to LDS, i.e. a whole
 //     patch after the loads were issued (applied at load time it waits for them: 1.94 instead of 1.20 ms); padding stays zero;
 //   * BatchNorm statistics (forward) / BatchNorm-backward sums (data gradient) accumulate in registers over ALL patches
 //     of a wave: one slab row per wave (deterministic: patches are dealt round-robin).  A wave's fp32 sums therefore run
-//     over ~130 patches (520 additions per accumulator) where a tile kernel's run over 16 rows: totals of two launches
-//     that split the batch differently agree to fp32 summation order (3e-5 relative), not bit for bit.
+//     over ~110 patches where a tile kernel's run over 16 rows: totals of two launches that split the batch differently
+//     agree to fp32 summation order (3e-5 relative), not bit for bit.
 // K order = the halo kernel's (32-channel chunk major, tap minor, one MFMA per output tile and step): outputs are
-// bit-identical to it (tests/test_gpu_c64.py).  Halo image: [6 rows][18 pixels][128 B], chunk ^= (hx >> 1) & 7 — sixteen
+// bit-identical to it (tests/test_gpu_c64.py).  Halo image: [9 rows][18 pixels][128 B], chunk ^= (hx >> 1) & 7 — sixteen
 // consecutive pixels of a row cover sixteen distinct 16-byte slots of the 256-byte bank row for any start (the row pitch is
 // even), and a halo row is a compile-time offset from three per-lane base addresses (one per kw).
-// Measured (B = 256, 224^2, scripts/pp_ab.py c64, medians): forward 1.57 -> 0.99 ms, normalise-on-load 1.70 -> 1.20 ms,
-// data gradient 2.0 -> 1.85 ms; the step 810.8 -> 818.6 images/s.  What bounds it as built (ablation builds, one box): the
-// compute side alone (K loop + LDS refill, no global traffic) 0.79 ms, the memory side alone (loads, stores, no MFMAs) 0.77-
-// 0.88 ms, together 1.1: LDS (72 KB of weights + 13.5 KB per wave) allows SIX waves on four SIMDs — two SIMDs carry two waves,
-// two carry one, there is little to overlap one wave's load wait and epilogue with, and the MFMA time is that of the
-// two-wave SIMDs (0.57 ms at best).  Requesting the data-gradient epilogue's operands before the K loop costs more in
-// spills than it hides (1.85 -> 2.15 ms).  Next: eight waves on 12 x 4 patches (84-pixel halos, 10.5 KB).
+// Measured (B = 256, 224^2, scripts/pp_ab.py c64, medians, halo kernel -> this): forward 1.57 -> 1.0 ms, normalise-on-load
+// 1.8 -> 1.1, data gradient (with the 0.6 ms clone the script adds to both arms) 2.63 -> 2.00; the step 808 -> 821 images/s.
+// What bounds it as built: each wave moves 35 KB per patch in 8.9 us — 4.0 TB/s over the chip — with the MFMA pipe 43 % busy:
+// neither roof.  Ablation builds (six-wave version, one box): compute side alone 0.79 ms, memory side alone 0.77-0.88 ms,
+// together 1.1: one wave per SIMD overlaps its own loads with its MFMAs, but its LDS refill, epilogue and scalar patch
+// arithmetic run with the matrix pipe idle.  Tried and dropped: requesting the data-gradient epilogue's operands before the K
+// loop (spills at 256 registers: 1.85 -> 2.15 ms), halo loads from inline assembly with a hand-counted s_waitcnt (hipcc copies
+// the destination registers before the wait: wrong results — the deferred stores above are the compiler-visible way to the
+// same end), plain instead of non-temporal halo loads (memory side alone -13 %, whole kernel unchanged).
 #include "conv_igemm.h"
 #include <type_traits>
 
@@ -44,16 +51,20 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N, I + 1>(f);
   }
 }
-constexpr int C64_NW = 6;                 // waves per workgroup
-constexpr int C64_HP = 18, C64_HR = 6;    // halo pitch (pixels) and rows
-constexpr int C64_HPX = C64_HP * C64_HR;  // 108 pixels
-constexpr int C64_HB = C64_HPX * 128;     // 13824 bytes
+constexpr int C64_NW = 4;                 // waves per workgroup: ONE per SIMD, up to 512 registers each
+// output rows per patch: 16 x 7 pixels (seven MFMA pixel tiles; 224 = 32 x 7) in the forward kernels, 16 x 6 in the data
+// gradient, whose epilogue needs the registers (16 x 7 there: 55 spilled)
+constexpr int c64_pr(int emode) { return emode == 6 ? 6 : 7; }
+constexpr int C64_HP = 18;                // halo pitch (pixels)
 constexpr int C64_WB = 9 * 64 * 128;      // 73728 bytes of weights
-constexpr int C64_NCH = (C64_HPX * 8 + 63) / 64;   // 14 16-byte chunks per lane per halo
+constexpr int c64_hb(int pr) { return C64_HP * (pr + 2) * 128; }   // bytes of one halo image: (pr + 2) rows x 18 pixels x 128 B
 }  // namespace
 
 template <int XF, int EMODE>
-__global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
+  constexpr int C64_PR = c64_pr(EMODE), C64_HR = C64_PR + 2, C64_HB = c64_hb(C64_PR);
+  constexpr int C64_NE = (C64_HR + 3) / 4;           // edge-column loads (four halo rows x two pixels each)
+  constexpr int C64_NCH = 2 * C64_HR + C64_NE;       // 16-byte chunks per lane per halo
   typedef bf16_t T;
   typedef Mma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
   T* __restrict__ y = reinterpret_cast<T*>(a.y);
   const int H = a.IH, W = a.IW;
-  const int tilesX = (W + 15) >> 4, tilesY = (H + 3) >> 2, tpi = tilesX * tilesY;
+  const int tilesX = (W + 15) >> 4, tilesY = (H + C64_PR - 1) / C64_PR, tpi = tilesX * tilesY;
   const int P = a.N * tpi;
   // wave index over the launch.  Workgroups go round-robin over the 8 XCDs (each with its own L2): the waves of one XCD
   // take CONTIGUOUS patches in every round, so that the halo rows and columns neighbouring patches share meet in one L2.
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
   // output channels): row t*16 + m of the image holds channel 32 (t >> 1) + 8 (m >> 2) + 4 (t & 1) + (m & 3), so that the
   // accumulators of tiles 2q, 2q+1 in one lane are EIGHT CONSECUTIVE channels of one pixel: the epilogue is 16-byte
   // row stores straight from the registers ----
-  for (int c = tid; c < 9 * 64 * 8; c += 384) {
+  for (int c = tid; c < 9 * 64 * 8; c += 64 * C64_NW) {
     const int ch = c & 7, row = c >> 3;            // row = tap*64 + t*16 + m
     const int tap = row >> 6, t = (row >> 4) & 3, m = row & 15;
     const int co = 32 * (t >> 1) + 8 * (m >> 2) + 4 * (t & 1) + (m & 3);
@@ -134,7 +145,7 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
     n = p / tpi;
     const int rem = p - n * tpi;
     const int ty = rem / tilesX;
-    oy0 = ty * 4;
+    oy0 = ty * C64_PR;
     ox0 = (rem - ty * tilesX) * 16;
   };
   auto xform = [&](uint4 v, bool ok) -> uint4 {
@@ -152,15 +163,17 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
     patch_origin(p, n, oy0, ox0);
     // halo origin = input pixel (oy0 - 1, ox0 - 1); rows are uniform, columns per lane
     const T* org = x + (((long long)n * H + (oy0 - 1)) * W + (ox0 - 1)) * 64;
-    if (oy0 >= 1 && oy0 + 5 <= H && ox0 >= 1 && ox0 + 17 <= W) {   // the whole halo is inside the image: no predicates
+    if (oy0 >= 1 && oy0 + C64_PR + 1 <= H && ox0 >= 1 && ox0 + 17 <= W) {   // the whole halo is inside the image: no predicates
 #pragma unroll
       for (int hy = 0; hy < C64_HR; ++hy)
 #pragma unroll
         for (int g = 0; g < 2; ++g) pre[hy * 2 + g] = ld16_nt(org + (long long)hy * W * 64 + lane * 8 + g * 512);
-      pre[12] = ld16_nt(org + geoff);
-      pre[13] = make_uint4(0, 0, 0, 0);
-      if (lane < 32) pre[13] = ld16_nt(org + (long long)4 * W * 64 + geoff);
-      prem = 0x3fffu;
+#pragma unroll
+      for (int e = 0; e < C64_NE; ++e) {
+        pre[2 * C64_HR + e] = make_uint4(0, 0, 0, 0);
+        if (4 * e + er < C64_HR) pre[2 * C64_HR + e] = ld16_nt(org + (long long)e * 4 * W * 64 + geoff);
+      }
+      prem = (1u << C64_NCH) - 1u;
       return;
     }
     const bool cok0 = ox0 - 1 + lx >= 0, cok1 = ox0 + 7 + lx < W;
@@ -179,13 +192,13 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
       }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < C64_NE; ++e) {
       const int hy = 4 * e + er;
       const bool ok = hy < C64_HR && (unsigned)(oy0 - 1 + hy) < (unsigned)H && ox0 + 15 + ej < W;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (ok) v = ld16_nt(org + (long long)e * 4 * W * 64 + geoff);
-      pre[12 + e] = v;
-      if (XF != 0 && ok) m |= 1u << (12 + e);
+      pre[2 * C64_HR + e] = v;
+      if (XF != 0 && ok) m |= 1u << (2 * C64_HR + e);
     }
     prem = m;
   };
@@ -196,8 +209,29 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
 #pragma unroll
       for (int g = 0; g < 2; ++g)
         *reinterpret_cast<uint4*>(hb + (sb0 ^ (g << 6)) + hy * (C64_HP * 128) + g * 1024) = xform(pre[hy * 2 + g], (prem >> (hy * 2 + g)) & 1u);
-    *reinterpret_cast<uint4*>(hb + sbe) = xform(pre[12], (prem >> 12) & 1u);
-    if (lane < 32) *reinterpret_cast<uint4*>(hb + sbe + 4 * C64_HP * 128) = xform(pre[13], (prem >> 13) & 1u);
+#pragma unroll
+    for (int e = 0; e < C64_NE; ++e)
+      if (4 * e + er < C64_HR)
+        *reinterpret_cast<uint4*>(hb + sbe + e * 4 * C64_HP * 128) = xform(pre[2 * C64_HR + e], (prem >> (2 * C64_HR + e)) & 1u);
+  };
+
+  // The output stores of a patch are DEFERRED to the next iteration, in front of the request for the halo after next.  With
+  // the stores issued right after the MFMAs they were younger than the halo loads in flight, and the waits hipcc derives
+  // for the LDS refill (it counts the loads only) then ran down to vmcnt(0): every refill waited for the previous patch's
+  // stores to be acknowledged — a microsecond with nothing else to run on the SIMD.  Deferred, nothing younger than the
+  // halo loads is in flight when they are waited for, and the stores had a whole K loop to retire.
+  uint4 outp[2 * C64_PR];   // the patch's packed bf16 rows, [r][q]
+  T* out_ptr = nullptr;     // where they go (per lane), nullptr: nothing pending
+  unsigned out_ok = 0;      // bit r: row r of the patch is inside the image for this lane
+  auto flush_out = [&]() {
+    if (out_ptr) {
+#pragma unroll
+      for (int r = 0; r < C64_PR; ++r) {
+        if (!((out_ok >> r) & 1u)) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint4*>(out_ptr + (long long)r * W * 64 + q * 32) = outp[r * 2 + q];
+      }
+    }
   };
 
   int p = gw;
@@ -206,26 +240,27 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
     int n, oy0, ox0;
     patch_origin(p, n, oy0, ox0);
     store_halo();
+    flush_out();
     const int pn = p + gstride;
     if (pn < P) load_halo(pn);     // in flight under this patch's MFMAs
 
-    f32x4 acc[4][4];               // [pixel row r][channel tile t]
+    f32x4 acc[C64_PR][4];               // [pixel row r][channel tile t]
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < C64_PR; ++r)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       // K loop, 18 steps (32-channel chunk major, tap minor).  Fragments are double-buffered by hand: the reads of step
       // k + 1 are issued before the 16 MFMAs of step k (one wave has at most one partner on its SIMD: LDS latency is not
       // hidden by occupancy here)
-      frag_t wf[2][4], pf[2][4];
+      frag_t wf[2][4], pf[2][C64_PR];
       auto ldfr = [&](auto stc, auto bc) {
         constexpr int st = decltype(stc)::value, b = decltype(bc)::value;
         constexpr int s = st / 9, tap = st % 9, kh = tap / 3, kw = tap % 3;
 #pragma unroll
         for (int t = 0; t < 4; ++t) wf[b][t] = *reinterpret_cast<const frag_t*>(wbs[s] + tap * 8192 + t * 2048);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pf[b][r] = *reinterpret_cast<const frag_t*>(hb + (aoff[kw] ^ (s ? 64 : 0)) + (r + kh) * (C64_HP * 128));
+        for (int r = 0; r < C64_PR; ++r) pf[b][r] = *reinterpret_cast<const frag_t*>(hb + (aoff[kw] ^ (s ? 64 : 0)) + (r + kh) * (C64_HP * 128));
       };
       ldfr(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
       static_for<18>([&](auto stc) {
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
         if constexpr (st + 1 < 18) ldfr(std::integral_constant<int, st + 1>(), std::integral_constant<int, b ^ 1>());
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < C64_PR; ++r)
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[r][t] = Mma<T>::run(wf[b][t], pf[b][r], acc[r][t]);
         __builtin_amdgcn_sched_barrier(0);
@@ -241,14 +276,14 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
     }
 
     // ---- epilogue, from the registers: lane (frow, fg) holds channels 32 q + 8 fg .. + 7 of pixel (oy0 + r, ox0 + frow) ----
-    const bool full = oy0 + 4 <= H && ox0 + 16 <= W;
+    const bool full = oy0 + C64_PR <= H && ox0 + 16 <= W;
     const bool colok = ox0 + frow < W;
     const long long yoff = (((long long)n * H + oy0) * W + ox0 + frow) * 64 + fg * 8;
     T* yp = y + yoff;
     if constexpr (EMODE == 0) {
       if (a.stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < C64_PR; ++r) {
           const bool ok = full || (colok && oy0 + r < H);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -260,27 +295,33 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
             }
         }
       }
+      out_ok = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (!(full || (colok && oy0 + r < H))) continue;
+      for (int r = 0; r < C64_PR; ++r) {
+        if (full || (colok && oy0 + r < H)) out_ok |= 1u << r;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x4 u = acc[r][2 * q], v = acc[r][2 * q + 1];
-          const uint4 o = make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-          *reinterpret_cast<uint4*>(yp + (long long)r * W * 64 + q * 32) = o;
+          outp[r * 2 + q] = make_uint4(pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
       }
+      out_ptr = yp;
     } else {
+      out_ok = 0;
+#pragma unroll
+      for (int r = 0; r < C64_PR; ++r)
+        if (full || (colok && oy0 + r < H)) out_ok |= 1u << r;
+      out_ptr = yp;
       const bool has_mask = a.mask != nullptr, from_y = a.ep1 && a.ep2;
       // (requesting these operands before the MFMAs was measured: the registers they hold through the K loop cost more
       //  in spills than the hidden latency gains — 1.85 -> 2.15 ms)
       const T* __restrict__ etp = reinterpret_cast<const T*>(a.et) + yoff;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        Vec16<T> vy[4];
-        unsigned mb8[4];
+        Vec16<T> vy[C64_PR];
+        unsigned mb8[C64_PR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < C64_PR; ++r) {
           vy[r].zero();
           mb8[r] = 0;
           if (full || (colok && oy0 + r < H)) {
@@ -299,16 +340,16 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
             q2[e] = cs[128 + e];
           }
         }
-        Vec16<T> vm[4];
-        bool ok[4];
+        Vec16<T> vm[C64_PR];
+        bool ok[C64_PR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < C64_PR; ++r) {
           ok[r] = full || (colok && oy0 + r < H);
           vm[r].zero();
           if (ok[r] && has_mask && !a.mask_bits) vm[r].load(reinterpret_cast<const T*>(a.mask) + yoff + (long long)r * W * 64 + q * 32);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < C64_PR; ++r) {
           if (!ok[r]) continue;
           const f32x4 u = acc[r][2 * q], v = acc[r][2 * q + 1];
           Vec16<T> o;
@@ -336,12 +377,13 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
             s1[q * 8 + e] += fv[e];
             s2[q * 8 + e] += fv[e] * (fy[e] - q0[e]);
           }
-          o.store(yp + (long long)r * W * 64 + q * 32);
+          outp[r * 2 + q] = o.raw;
         }
       }
     }
     p = pn;
   }
+  flush_out();
 
   // ---- one slab row per wave: sums over the 16 pixel lanes of each channel group ----
   const int srow = blockIdx.x * C64_NW + wid;
@@ -363,9 +405,9 @@ __global__ __launch_bounds__(384, 2) void conv_c64_kernel(ConvArgs a) {
   }
 }
 
-// Workgroups launched for this geometry (slab rows = 6 per workgroup): one per CU, fewer for small inputs.
+// Workgroups launched for this geometry (slab rows = one per wave): one per CU, fewer for small inputs.
 int maai_conv_c64_rows(const ConvArgs& a) {
-  const long long P = (long long)a.N * ((a.IW + 15) / 16) * ((a.IH + 3) / 4);
+  const long long P = (long long)a.N * ((a.IW + 15) / 16) * ((a.IH + 6) / 7);   // (16 x 7 patches: the coarser of the two sizes)
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -378,7 +420,7 @@ bool maai_conv_c64_supported(const ConvArgs& a, int dtype) {
   if (dtype != MAAI_BF16 || a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad_h != 1 || a.pad_w != 1 || a.Cin != 64 || a.Cout != 64) return false;
   if (a.OHg != a.IH || a.OWg != a.IW || a.OH != a.OHg || a.OW != a.OWg || a.ostr != 1 || a.ooh || a.oow) return false;
   if (a.xb || a.a2 || a.pre_x || a.accumulate) return false;
-  if ((long long)a.N * ((a.IW + 15) / 16) * ((a.IH + 3) / 4) >= (1ll << 30)) return false;   // (32-bit patch arithmetic)
+  if ((long long)a.N * ((a.IW + 15) / 16) * ((a.IH + 5) / 6) >= (1ll << 30)) return false;   // (32-bit patch arithmetic)
   if (a.emode == MAAI_EPI_STORE) return !a.mask;
   if (a.emode == MAAI_EPI_DGRAD_REDUCE) return a.et && !a.xs;
   return false;
@@ -386,11 +428,11 @@ bool maai_conv_c64_supported(const ConvArgs& a, int dtype) {
 
 template <int XF, int EMODE>
 static int launch_c64(const ConvArgs& a, hipStream_t st) {
-  constexpr int lds = C64_WB + C64_NW * C64_HB + 320 * 4;   // weights | six halo images | coefficient tables
+  constexpr int lds = C64_WB + C64_NW * c64_hb(c64_pr(EMODE)) + 320 * 4;   // weights | one halo image per wave | coefficient tables
   static int attr[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_c64_kernel<XF, EMODE>), lds, attr);
   const int grid = maai_conv_c64_rows(a) / C64_NW;
-  hipLaunchKernelGGL((conv_c64_kernel<XF, EMODE>), dim3((unsigned)grid), dim3(384), lds, st, a);
+  hipLaunchKernelGGL((conv_c64_kernel<XF, EMODE>), dim3((unsigned)grid), dim3(64 * C64_NW), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

@@ -212,8 +212,8 @@ static bool c64_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
     return false;
   }
   if (mode == 2) return true;
-  const long long patches = (long long)d->N * ((d->IW + 15) / 16) * ((d->IH + 3) / 4);
-  return patches >= 8192 && d->IW % 16 == 0 && d->IH % 4 == 0;
+  const long long patches = (long long)d->N * ((d->IW + 15) / 16) * ((d->IH + 6) / 7);
+  return patches >= 8192 && d->IW % 16 == 0 && d->IH >= 96;   // (16 x 6 patches: a ragged last row of patches costs < 6 % from 96 rows up)
 }
 static long long c64_rows(const maai_conv_desc* d) {
   ConvArgs a;
@@ -249,10 +249,14 @@ static bool pp_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi, 
   //   1x1: 1024->256@56 0.57 -> 0.48, 2048->512@28 0.50 -> 0.41, 1024->512@56 1.02 -> 0.88, 1024->2048@28 0.95 -> 0.84,
   //        512->256@112 1.30 -> 1.16; the channel-expanding ones lose (256->1024@56: 0.64 -> 0.81, streaming kernel) or tie
   //        (512->2048@28 0.57 -> 0.56).
-  const char* r = getenv("MAAI_CONV_PP_RULE");   // experiment knob: bit 0 = 3x3 >= 256 channels, 1 = long-K 1x1, 2 = 128-channel 3x3
-  const int rule = r ? atoi(r) : 3;
+  const char* r = getenv("MAAI_CONV_PP_RULE");   // experiment knob: bit 0 = 3x3 >= 256 channels, 1 = long-K 1x1, 2 = 128-channel 3x3, 3 = 1:4 expanding 1x1 with the BN_ACT epilogue (eval forward 55.0 -> 54.45 ms)
+  const int rule = r ? atoi(r) : 11;
   if (d->KH * d->KW >= 9) return d->Cout % 256 == 0 ? (rule & 1) && d->Cin >= 256 : (rule & 4) && d->Cin >= 128;
-  if (d->KH * d->KW == 1) return (rule & 2) && d->Cout % 256 == 0 && d->Cin >= 512 && d->Cout <= 2 * d->Cin;
+  // (rule bit 3: with the frozen-BatchNorm epilogue also the 1:4 expanding layers — 512->2048@28 — whose plain launch ties
+  //  with the ring kernel's 128 x 256 tile, but whose fused epilogue there is slow)
+  if (d->KH * d->KW == 1)
+    return (rule & 2) && d->Cout % 256 == 0 && d->Cin >= 512 &&
+           (d->Cout <= 2 * d->Cin || ((rule & 8) && emode == MAAI_EPI_BN_ACT && d->Cout <= 4 * d->Cin));
   return false;
 }
 
