@@ -28,9 +28,8 @@
 //     over ~110 patches where a tile kernel's run over 16 rows: totals of two launches that split the batch differently
 //     agree to fp32 summation order (3e-5 relative), not bit for bit.
 // K order = the halo kernel's (32-channel chunk major, tap minor, one MFMA per output tile and step): outputs are
-// bit-identical to it (tests/test_gpu_c64.py).  Halo image: [9 rows][18 pixels][128 B], chunk ^= (hx >> 1) & 7 — sixteen
-// consecutive pixels of a row cover sixteen distinct 16-byte slots of the 256-byte bank row for any start (the row pitch is
-// even), and a halo row is a compile-time offset from three per-lane base addresses (one per kw).
+// bit-identical to it (tests/test_gpu_c64.py).  Halo image: [9 rows][18 pixels][128 B], chunk ^= c64_key(hx) (below: conflict-
+// free for the lane groups ds_read_b128 is really served in), and a halo row is a compile-time offset from three per-lane base addresses (one per kw).
 // Measured (B = 256, 224^2, scripts/pp_ab.py c64, medians, halo kernel -> this): forward 1.57 -> 1.0 ms, normalise-on-load
 // 1.8 -> 1.1, data gradient (with the 0.6 ms clone the script adds to both arms) 2.63 -> 2.00; the step 808 -> 821 images/s.
 // What bounds it as built: each wave moves 35 KB per patch in 8.9 us — 4.0 TB/s over the chip — with the MFMA pipe 43 % busy:
@@ -39,7 +38,10 @@
 // arithmetic run with the matrix pipe idle.  Tried and dropped: requesting the data-gradient epilogue's operands before the K
 // loop (spills at 256 registers: 1.85 -> 2.15 ms), halo loads from inline assembly with a hand-counted s_waitcnt (hipcc copies
 // the destination registers before the wait: wrong results — the deferred stores above are the compiler-visible way to the
-// same end), plain instead of non-temporal halo loads (memory side alone -13 %, whole kernel unchanged).
+// same end), plain instead of non-temporal halo loads and non-temporal output stores (MAAI_EXP 16 / 32 builds, interleaved
+// A/B: all within +-2 %).  The halo swizzle below removed every LDS bank conflict (SQ_LDS_BANK_CONFLICT 25.8 % -> 0.0 % of the
+// LDS cycles) and 0.3 % of the time: the kernel runs at ~4 TB/s of HBM traffic (PMC: 3.88 GB per forward launch against 3.29
+// algorithmic — part of the halo overlap is fetched twice), 70 % of what the streaming BatchNorm passes reach.
 #include "conv_igemm.h"
 #include <type_traits>
 
@@ -51,6 +53,24 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N, I + 1>(f);
   }
 }
+// Halo swizzle: the 16-byte chunk c of halo pixel hx lives at chunk slot c ^ c64_key(hx) of the pixel's 128 bytes.
+// ds_read_b128 is served in four groups of sixteen lanes that are NOT lane-contiguous — {0-3, 12-15, 20-27}, {4-11, 16-19,
+// 28-31}, ... (MI355X_MICROARCH.md, LDS): a group reads pixels frow in {0-3, 12-15} at one K-chunk and frow in {4-11} at the
+// NEXT one.  The textbook key (hx >> 1) & 7 is conflict-free for sixteen consecutive pixels at ONE chunk; with the real
+// groups it collides for the taps kw = 1, 2 (two of sixteen slots double: 25.8 % of the kernel's LDS cycles were bank
+// conflicts, SQ_LDS_BANK_CONFLICT).  This key — bit 1 = hx bit 2, bit 2 = hx bit 1 — is conflict-free for kw = 0, 1, 2
+// and both group shapes (exhaustive search over the GF(2)-linear keys, scripts in DESIGN.md section 4).
+#if MAAI_EXP & 16   // A/B builds (scripts/build_variant.sh): plain instead of non-temporal halo loads / non-temporal output stores
+#define C64_LD(p) (*reinterpret_cast<const uint4*>(p))
+#else
+#define C64_LD(p) ld16_nt(p)
+#endif
+#if MAAI_EXP & 32
+#define C64_ST(p, v) st16_nt(p, v)
+#else
+#define C64_ST(p, v) (*reinterpret_cast<uint4*>(p) = (v))
+#endif
+__device__ __forceinline__ constexpr int c64_key(int hx) { return (((hx >> 2) & 1) << 1) | (((hx >> 1) & 1) << 2); }
 constexpr int C64_NW = 4;                 // waves per workgroup: ONE per SIMD, up to 512 registers each
 // output rows per patch: 16 x 7 pixels (seven MFMA pixel tiles; 224 = 32 x 7) in the forward kernels, 16 x 6 in the data
 // gradient, whose epilogue needs the registers (16 x 7 there: 55 spilled)
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
   // ---- halo staging: 12 "body" loads (halo row hy, pixels 8g .. 8g+7: lane = pixel*8 + chunk, 1 KB contiguous) and 2
   // "edge" loads (pixels 16, 17 of four rows at a time) per patch ----
   const int lx = lane >> 3, lch = lane & 7;
-  const int sb0 = lx * 128 + ((lch ^ (lx >> 1)) << 4);                         // body, g = 0; g = 1: ^ 64, + 1024
+  const int sb0 = lx * 128 + ((lch ^ c64_key(lx)) << 4);                       // body (c64_key(8 g + lx) == c64_key(lx)); g = 1: + 1024
   const int er = lane >> 4, ej = (lane >> 3) & 1;
   const int sbe = er * (C64_HP * 128) + (16 + ej) * 128 + (lch << 4);         // edge ((16 + j) >> 1 & 7 == 0: no swizzle)
   const int geoff = (er * W + 16 + ej) * 64 + lch * 8;                         // edge: element offset from the halo origin
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     const int hx = kw + frow;
-    aoff[kw] = hx * 128 + ((fg ^ ((hx >> 1) & 7)) << 4);
+    aoff[kw] = hx * 128 + ((fg ^ c64_key(hx)) << 4);
   }
   const char* wbs[2];    // weights (A operand): image row t*16 + frow, chunk s*4 + fg
 #pragma unroll
@@ -167,11 +187,11 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
 #pragma unroll
       for (int hy = 0; hy < C64_HR; ++hy)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) pre[hy * 2 + g] = ld16_nt(org + (long long)hy * W * 64 + lane * 8 + g * 512);
+        for (int g = 0; g < 2; ++g) pre[hy * 2 + g] = C64_LD(org + (long long)hy * W * 64 + lane * 8 + g * 512);
 #pragma unroll
       for (int e = 0; e < C64_NE; ++e) {
         pre[2 * C64_HR + e] = make_uint4(0, 0, 0, 0);
-        if (4 * e + er < C64_HR) pre[2 * C64_HR + e] = ld16_nt(org + (long long)e * 4 * W * 64 + geoff);
+        if (4 * e + er < C64_HR) pre[2 * C64_HR + e] = C64_LD(org + (long long)e * 4 * W * 64 + geoff);
       }
       prem = (1u << C64_NCH) - 1u;
       return;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
       for (int g = 0; g < 2; ++g) {
         const bool ok = rok && (g ? cok1 : cok0);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) v = ld16_nt(rp + g * 512);
+        if (ok) v = C64_LD(rp + g * 512);
         pre[hy * 2 + g] = v;
         if (XF != 0 && ok) m |= 1u << (hy * 2 + g);
       }
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
       const int hy = 4 * e + er;
       const bool ok = hy < C64_HR && (unsigned)(oy0 - 1 + hy) < (unsigned)H && ox0 + 15 + ej < W;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = ld16_nt(org + (long long)e * 4 * W * 64 + geoff);
+      if (ok) v = C64_LD(org + (long long)e * 4 * W * 64 + geoff);
       pre[2 * C64_HR + e] = v;
       if (XF != 0 && ok) m |= 1u << (2 * C64_HR + e);
     }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
     for (int hy = 0; hy < C64_HR; ++hy)
 #pragma unroll
       for (int g = 0; g < 2; ++g)
-        *reinterpret_cast<uint4*>(hb + (sb0 ^ (g << 6)) + hy * (C64_HP * 128) + g * 1024) = xform(pre[hy * 2 + g], (prem >> (hy * 2 + g)) & 1u);
+        *reinterpret_cast<uint4*>(hb + sb0 + hy * (C64_HP * 128) + g * 1024) = xform(pre[hy * 2 + g], (prem >> (hy * 2 + g)) & 1u);
 #pragma unroll
     for (int e = 0; e < C64_NE; ++e)
       if (4 * e + er < C64_HR)
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
       for (int r = 0; r < C64_PR; ++r) {
         if (!((out_ok >> r) & 1u)) continue;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint4*>(out_ptr + (long long)r * W * 64 + q * 32) = outp[r * 2 + q];
+        for (int q = 0; q < 2; ++q) C64_ST(out_ptr + (long long)r * W * 64 + q * 32, outp[r * 2 + q]);
       }
     }
   };

@@ -436,6 +436,30 @@ def _exchange(kind, vecs):
     return res
 
 
+# nn.BatchNorm2d.num_batches_tracked += 1 (torch/nn/modules/batchnorm.py: every training forward).  Inside backbone_fwd the
+# increments of a whole forward are collected and applied by ONE torch._foreach_add_ (53 tiny launches -> 1 per forward);
+# a unit driven on its own (tests, the head) is incremented at once.
+_NBT = {"depth": 0, "pending": []}
+
+
+def _count_batch(bn):
+    if _NBT["depth"] > 0:
+        _NBT["pending"].append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
+class _batched_counters(object):
+    def __enter__(self):
+        _NBT["depth"] += 1
+
+    def __exit__(self, et, ev, tb):
+        _NBT["depth"] -= 1
+        if _NBT["depth"] == 0 and _NBT["pending"]:
+            pend, _NBT["pending"] = _NBT["pending"], []
+            torch._foreach_add_(pend, 1)
+
+
 def _drive(gen):
     """Run a unit generator to completion; it yields (kind, vector) at most once when a cross-rank exchange is due and
     continues with the exchanged result."""
@@ -602,9 +626,11 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             count *= world   # (every rank runs the same per-GPU batch: what the backward's 1/count uses)
         mom = bn.momentum
         if bn.track_running_stats and bn.running_mean is not None:
-            bn.num_batches_tracked += 1
             if mom is None:
+                bn.num_batches_tracked += 1
                 mom = 1.0 / float(bn.num_batches_tracked)
+            else:
+                _count_batch(bn)   # (one multi-tensor increment per forward instead of one tiny launch per layer)
             rm, rv = bn.running_mean, bn.running_var
         else:
             rm = rv = None
@@ -1036,6 +1062,11 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
 
 def backbone_fwd(resnet, x, dtype, keep):
     """resnet.py:226-240.  Returns (NHWC feature map, tape)."""
+    with _batched_counters():
+        return _backbone_fwd(resnet, x, dtype, keep)
+
+
+def _backbone_fwd(resnet, x, dtype, keep):
     xs, wq, form = stem_input(x, resnet.conv1, dtype)
     tape = []
     cin = resnet.conv1.weight.shape[1]
