@@ -100,8 +100,10 @@ def test_fast_rule(K):
     assert K.conv_bn_act_fast(c, 256, 112, 112, bf)
 
 
-def test_eval_forward_with_fast_rule_equals_pass_path():
-    """ResNet-50 eval forward (frozen statistics) at 64^2 x 8: rule on == rule off, bit for bit; and fewer BatchNorm passes"""
+@pytest.mark.parametrize("arch,size,batch", [("resnet50", 64, 8), ("resnet18", 64, 8), ("resnet50", 224, 4)])
+def test_eval_forward_with_fast_rule_equals_pass_path(arch, size, batch):
+    """eval forward (frozen statistics): rule on == rule off, bit for bit, and fewer BatchNorm passes — bottleneck and basic
+    blocks, and at 224^2 the shapes whose launches take the streaming / chained / persistent kernels"""
     PKG = os.path.join(ROOT, "multimodal-active-ai_amd")
     SIM = os.path.join(PKG, "SimCLR")
     for d in (PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP")):
@@ -110,7 +112,7 @@ def test_eval_forward_with_fast_rule_equals_pass_path():
     import resnet as rn
     from maai_hip import engine, kernels as K
     torch.manual_seed(3)
-    f = rn.resnet50(crop_measures=1).cuda()
+    f = getattr(rn, arch)(crop_measures=1).cuda()
     for m in f.modules():   # non-trivial running statistics
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.2)
@@ -118,7 +120,7 @@ def test_eval_forward_with_fast_rule_equals_pass_path():
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.2)
     f.eval()
-    x = torch.randint(0, 256, (8, 3, 64, 64), device="cuda").float()
+    x = torch.randint(0, 256, (batch, 3, size, size), device="cuda").float()
     dtype = torch.bfloat16
     outs, passes = [], []
     old = dict(engine._EVAL_FUSE)
