@@ -48,6 +48,7 @@ CASES = [
     ("ping-pong 3x3 256 stride 2", dict(MAAI_CONV_PP="2"), (2, 28, 28, 256, 256, 3, 2), False),
     ("ping-pong 1x1 1024->256", dict(MAAI_CONV_PP="2"), (2, 15, 14, 1024, 256, 1, 1), False),
     ("ping-pong 1x1 512->2048", dict(MAAI_CONV_PP="2"), (3, 7, 7, 512, 2048, 1, 1), False),
+    ("ping-pong persistent 1x1 1024->256", dict(MAAI_CONV_PP="2"), (8, 96, 96, 1024, 256, 1, 1), False),
     ("ping-pong 3x3 512 ragged", dict(MAAI_CONV_PP="2"), (1, 9, 7, 512, 512, 3, 1), False),
     ("halo 3x3 128", dict(MAAI_CONV_HALO="1", MAAI_CONV_PP="0"), (2, 30, 32, 128, 128, 3, 1), False),
     ("halo 3x3 64", dict(MAAI_CONV_HALO="1", MAAI_CONV_C64="0"), (2, 33, 20, 64, 64, 3, 1), False),

@@ -51,6 +51,10 @@ CASES = [
     (2, 17, 17, 128, 256, 3, 2),     # stride 2, odd extent
     (4, 8, 8, 1024, 256, 1, 1),      # channel-reducing pointwise, M = 256 exactly
     (1, 20, 20, 320, 768, 3, 1),     # 5 K-tiles per tap (45 in all), three column tiles
+    # more tiles than CUs: the persistent form (conv_ppp.hip) walks several tiles per workgroup — epilogue behind the next
+    # tile's prologue, stores counted in its first waits
+    (8, 96, 96, 256, 256, 1, 1),     # 288 tiles, 4 K-tiles (the minimum it takes)
+    (7, 97, 99, 64, 512, 3, 1),      # 263 row tiles x 2 column tiles, the last row tile ragged, 9 K-tiles
     # 128-channel outputs: the 4 x 2 wave grid (512 x 128 tiles, all 160 KB of LDS)
     (2, 14, 14, 128, 128, 3, 1),     # M = 392 < one tile
     (3, 23, 23, 128, 128, 3, 1),     # M = 1587: three full tiles and a ragged one
@@ -93,6 +97,7 @@ def test_pingpong_forward_matches_ring_kernel(K, case):
 
 DG_CASES = [
     # N, H, W, C (of dy = Cout of the forward layer), Cb (channels of the unit below = the gradient's output), k
+    (8, 96, 97, 128, 256, 3),        # 291 tiles, the last ragged: the persistent form
     (2, 14, 14, 256, 256, 3),
     (3, 15, 15, 512, 256, 1),
     (1, 9, 11, 128, 256, 3),
