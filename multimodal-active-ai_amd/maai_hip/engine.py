@@ -230,13 +230,22 @@ class _Rec(object):
 _FUSE = {"max_cin": int(os.environ.get("MAAI_FUSE_MAX_CIN", "0")),
          # the same recompute trade for forward passes that keep nothing for a backward (the no-grad view of the
          # SimCLR step, evaluation): only the two forward conv passes are paid, none of the backward ones
-         "nograd_max_cin": int(os.environ.get("MAAI_FUSE_NOGRAD_MAX_CIN", "0"))}
+         # Round 3: ON for the expanding pointwise units with 128 .. 256 input channels (conv3 of stages 2-3).  With the
+         # streaming kernel's statistics-only and BatchNorm-epilogue launches (both take the lazy input, the second adds the
+         # shortcut) the unit is a 0.3 ms + 0.8 .. 1.4 ms pair instead of launch + join (pass, or join on load in the next conv1):
+         # the SimCLR step 820.0 / 822.2 -> 829.8 / 832.7 images/s (interleaved, one box).  Bit-identical to the unfused path.
+         "nograd_max_cin": int(os.environ.get("MAAI_FUSE_NOGRAD_MAX_CIN", "256")),
+         # ... from this many input channels up (64-channel units are the chained block boundaries of layer 1, which beat it)
+         "nograd_min_cin": int(os.environ.get("MAAI_FUSE_NOGRAD_MIN_CIN", "128"))}
 
 
 def _fusable(conv, form, keep=True):
-    lim = _FUSE["max_cin"] if keep else max(_FUSE["max_cin"], _FUSE["nograd_max_cin"])
-    return (form == "fwd" and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
-            and conv.in_channels <= lim and conv.out_channels >= 4 * conv.in_channels)
+    if not (form == "fwd" and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.out_channels >= 4 * conv.in_channels):
+        return False
+    if conv.in_channels <= _FUSE["max_cin"]:
+        return True
+    return (not keep) and _FUSE["nograd_min_cin"] <= conv.in_channels <= _FUSE["nograd_max_cin"]
 
 
 def _bn_training(bn):
@@ -578,7 +587,11 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         eval_lazy = isinstance(x, K.Lazy)
     # (a layer stays on ONE kernel family whatever form its input has: the families sum the statistics slab in different
     #  orders, and the ping-pong kernel of conv_pp.hip takes tensors only — a lazy input to one of its layers is materialised)
-    if isinstance(x, K.Lazy) and (fused or (eval_fused and not eval_lazy) or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
+    # (a fused unit — statistics-only launch + BatchNorm-epilogue launch — forms a single-tensor lazy input on load in both
+    #  launches where the streaming kernel takes the shape; not when a backward pass will recompute the convolution from x)
+    fused_lazy = (fused and not keep and isinstance(x, K.Lazy) and x.b is None and x.pre is None and dtype == torch.bfloat16
+                  and K.conv_bn_act_fast(conv, x.shape[0], x.shape[1], x.shape[2], dtype, lazy=True))
+    if isinstance(x, K.Lazy) and ((fused and not fused_lazy) or (eval_fused and not eval_lazy) or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
                                   or K.conv_module_family(conv, x.shape[0], x.shape[1], x.shape[2], dtype) == 2):
         x = materialise(x)
         if side is not None:
@@ -648,7 +661,8 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         if not fused and not chain:
             y = conv_x(False)
         mean = invstd = None
-        count, world = (x.numel() // x.shape[-1] if fused else (y.numel() // y.shape[-1] if y is not None else 0)), 1
+        xt = x.y if isinstance(x, K.Lazy) else x
+        count, world = (xt.numel() // xt.shape[-1] if fused else (y.numel() // y.shape[-1] if y is not None else 0)), 1
     if isinstance(branch, list):
         branch = branch[0]   # the shortcut branch, finalised by the same exchange (_drive_pair)
     xb = side["joined"] if (side is not None and isinstance(x, K.Lazy) and x.b is not None) else x  # what the backward reads

@@ -138,3 +138,44 @@ def test_eval_forward_with_fast_rule_equals_pass_path(arch, size, batch):
     torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
     assert passes[1] < passes[0], passes
+
+
+@pytest.mark.parametrize("size,batch", [(64, 8), (128, 4)])
+def test_nograd_training_forward_with_fused_units_equals_unfused(size, batch):
+    """The no-grad view of the SimCLR step (training-mode BatchNorm, nothing kept for a backward): conv3 of stages 2-3 as a
+    statistics-only launch + a BatchNorm-epilogue launch (engine._FUSE nograd rule) == launch + join, bit for bit — features
+    and running statistics"""
+    PKG = os.path.join(ROOT, "multimodal-active-ai_amd")
+    SIM = os.path.join(PKG, "SimCLR")
+    for d in (PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP")):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import copy
+    import resnet as rn
+    from maai_hip import engine, kernels as K
+    torch.manual_seed(5)
+    f0 = rn.resnet50(crop_measures=1).cuda()
+    for m in f0.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    x = torch.randint(0, 256, (batch, 3, size, size), device="cuda").float()
+    outs, stats, launches = [], [], []
+    old = dict(engine._FUSE)
+    try:
+        for lim in (0, 256):
+            engine._FUSE["nograd_max_cin"] = lim
+            f = copy.deepcopy(f0)
+            f.train()
+            with torch.no_grad(), K.profile() as prof:
+                o, _ = engine.backbone_fwd(f, x, torch.bfloat16, keep=False)
+            outs.append(o.clone())
+            stats.append([b.clone() for n, b in f.named_buffers()])
+            launches.append(sum(v["launches"] for k, v in prof.table().items() if k.startswith("bn_act_fwd")))
+    finally:
+        engine._FUSE.update(old)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    for a, b in zip(stats[0], stats[1]):
+        assert torch.equal(a, b)
+    assert launches[1] < launches[0], launches
