@@ -575,7 +575,9 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     training = False if frozen else (bn.training or (bn.running_mean is None))
     kh, kw = wq.shape[1], wq.shape[2]
     pad_w = pad if kw > 1 else 0
-    fused = _fusable(conv, form, keep) and not defer and branch is None and given is None
+    # (a "light" forward — the first pass of a recomputed block — keeps its records for their statistics only: it takes the
+    #  forms of a forward without a backward)
+    fused = _fusable(conv, form, keep and not light) and not defer and branch is None and given is None
     rows_out = (x.shape[0] * ((x.shape[1] + 2 * pad - kh) // stride + 1) * ((x.shape[2] + 2 * pad_w - kw) // stride + 1))
     eval_ok = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
                and wq.shape[0] % 64 == 0)
@@ -589,7 +591,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     #  orders, and the ping-pong kernel of conv_pp.hip takes tensors only — a lazy input to one of its layers is materialised)
     # (a fused unit — statistics-only launch + BatchNorm-epilogue launch — forms a single-tensor lazy input on load in both
     #  launches where the streaming kernel takes the shape; not when a backward pass will recompute the convolution from x)
-    fused_lazy = (fused and not keep and isinstance(x, K.Lazy) and x.b is None and x.pre is None and dtype == torch.bfloat16
+    fused_lazy = (fused and (not keep or light) and isinstance(x, K.Lazy) and x.b is None and x.pre is None and dtype == torch.bfloat16
                   and K.conv_bn_act_fast(conv, x.shape[0], x.shape[1], x.shape[2], dtype, lazy=True))
     if isinstance(x, K.Lazy) and ((fused and not fused_lazy) or (eval_fused and not eval_lazy) or form != "fwd" or not _lazy_input_ok(x, conv, dtype)
                                   or K.conv_module_family(conv, x.shape[0], x.shape[1], x.shape[2], dtype) == 2):
