@@ -47,7 +47,7 @@ for d in (ROOT, PKG, SIM, os.path.join(SIM, "ResNet"), os.path.join(SIM, "MLP"))
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters): dense bf16 MFMA, HBM3E
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-PMC_SUMMARY = "r03_pmc_traffic_b256.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/profile_round.sh)
+PMC_SUMMARY = "r04_pmc_traffic_b256.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/profile_round.sh)
 
 
 def csrc_digest():
@@ -74,7 +74,9 @@ def parse():
     ap.add_argument("--temperature", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU steps (after one untimed warm-up step); the median is reported")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps; the median is reported (BASELINE.md section 3: >= 10)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed CPU warm-up steps (BASELINE.md section 3: 3)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads (default: every core this process may use)")
     ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
     ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
     ap.add_argument("--recompute", action="store_true",
@@ -97,13 +99,11 @@ def self_launch(args):
     """``python3 bench.py --gpus N`` (N > 1) without a launcher: start ``python -m torch.distributed.run`` with the same
     arguments as a CHILD process and return its exit code.  Called before anything in this process has touched the GPU
     (and the GPU is never touched here afterwards: the parent only waits)."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT picks and holds (no bind-and-close race with other launches
+    # on a shared box, ADVICE r3); --local-addr: the container hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("[bench] --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd)))
     sys.stderr.flush()
     env = dict(os.environ)
@@ -185,39 +185,83 @@ def make_step(args, model, opt, device, rank, world):
     return step
 
 
+def host_cpu():
+    """(model name, physical cores of the host, logical CPUs this process may run on, CPU-time quota of its cgroup or None)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                k, _, v = ln.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except AttributeError:
+        logical = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return model, (len(cores) or None), logical, quota
+
+
 def cpu_baseline(args):
-    """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload: one untimed warm-up step,
-    then ``--cpu-steps`` timed steps of ``--cpu-batch`` images; the median step time is reported."""
+    """The oracle (a CPU port, fp32 torch-CPU ops) on a bounded sample of the same workload, BASELINE.md section 3's protocol:
+    ``--cpu-warmup`` (3) untimed steps, then ``--cpu-steps`` (10) timed steps of ``--cpu-batch`` images; the median step time
+    is reported, with the CPU model and the cores used."""
     import statistics
     from oracle import simclr_oracle as O
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 16)))  # a one-GPU box's CPU share is 16 cores
+    model, phys, logical, quota = host_cpu()
+    # every core this process may use: its affinity mask, capped by its cgroup's CPU-time quota when it has one (more threads
+    # than that only fight each other) and by the host's physical cores (SMT siblings do not add fp32 throughput)
+    limit = min(logical, phys) if phys else logical
+    how = "affinity %d logical CPUs, %s physical cores" % (logical, phys if phys else "?")
+    if quota is not None and quota >= 1 and quota < limit:
+        limit = int(quota)
+        how += ", cgroup quota %.1f CPUs" % quota
+    if args.cpu_threads > 0:
+        limit = args.cpu_threads
+        how += ", --cpu-threads %d" % args.cpu_threads
+    torch.set_num_threads(max(1, limit))
     b = args.cpu_batch
     exp = O.expansion(args.arch)
     sd = O.pattern_state_dict(args.arch, 1, 512 * exp * 16)
     imgs = synthetic_images(2 * b, args.img, torch.device("cpu"), 99).permute(0, 3, 1, 2).float().contiguous()
     x1, x2 = imgs[:b], imgs[b:]
     opt = {}
-    sys.stderr.write("[bench] cpu baseline: %d threads, batch %d, 1 warm-up + %d timed steps ...\n" % (torch.get_num_threads(), b, args.cpu_steps))
+    sys.stderr.write("[bench] cpu baseline: %s, %d threads (%s), batch %d, %d warm-up + %d timed steps ...\n"
+                     % (model, torch.get_num_threads(), how, b, args.cpu_warmup, args.cpu_steps))
     sys.stderr.flush()
     times = []
-    for i in range(args.cpu_steps + 1):
+    for i in range(args.cpu_warmup + args.cpu_steps):
         t0 = time.time()
         O.train_step(sd, opt, x1, x2, args.arch, args.temperature, 1e-3, pool=4)
         dt = time.time() - t0
-        if i > 0:
+        if i >= args.cpu_warmup:
             times.append(dt)
-        sys.stderr.write("[bench] cpu baseline step %d: %.1f s%s\n" % (i, dt, " (warm-up, not counted)" if i == 0 else ""))
+        sys.stderr.write("[bench] cpu baseline step %d: %.1f s%s\n" % (i, dt, " (warm-up, not counted)" if i < args.cpu_warmup else ""))
         sys.stderr.flush()
     med = statistics.median(times)
     return dict(value=round(b / med, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample="%s 3x%dx%d, batch %d, median of %d steps after 1 warm-up step (fp32, torch-CPU oracle); step times %s s; "
-                       "bounded sample: BASELINE.md section 3 asks for 3 warm-up + >= 10 timed CPU steps (~2 min here), this default "
-                       "run keeps 1 + %d so that bench.py finishes within minutes (--cpu-steps 10 runs the full protocol)"
-                       % (args.arch, args.img, args.img, b, args.cpu_steps, ["%.1f" % t for t in times], args.cpu_steps))
+                cpu_model=model, host_physical_cores=phys, usable_logical_cpus=logical, threads_chosen_from=how,
+                sample="%s 3x%dx%d, batch %d, median of %d timed steps after %d warm-up steps (BASELINE.md section 3's protocol; fp32, "
+                       "torch-CPU oracle, %d threads); step times min %.1f / median %.1f / max %.1f s"
+                       % (args.arch, args.img, args.img, b, args.cpu_steps, args.cpu_warmup, torch.get_num_threads(), min(times), med, max(times)))
 
 
 def main():
@@ -261,16 +305,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    losses = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-        losses.append(loss)   # device scalars: read after the timed region
-    barrier()
-    dt = time.perf_counter() - t0
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        losses = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+            losses.append(loss)   # device scalars: read after the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+    except torch.cuda.OutOfMemoryError as e:
+        # the program is fixed by the flags (no free-memory probe picks another one behind the user's back): say which flag helps
+        hint = ("MAAI_RECOMPUTE_LAYERS=1,2,3 recomputes stage 3 as well (-~60 GB at 512 images)" if args.recompute
+                else "--recompute rebuilds the blocks of stages 1-2 in the backward instead of storing their activations")
+        raise SystemExit("bench.py: out of HBM at --batch %d (recompute %s): %s\n%s" % (args.batch, rc_layers if args.recompute else "off", hint, e))
     losses = [float(v.item()) for v in losses]
     if not all(v == v and abs(v) < 1e30 for v in losses):
         raise SystemExit("bench.py: the loss is not finite over the timed steps: %s" % losses)
@@ -288,6 +338,7 @@ def main():
     with K.profile() as prof:
         step()
     table = prof.table()
+    ktable = prof.kernel_table()
     if args.detail:
         K.DETAIL[0] = True
         with K.profile() as prof2:
@@ -322,6 +373,21 @@ def main():
             roof = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(f_mfma, 4), **common)
         else:
             roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(f_hbm, 4), **common)
+        # the five DEVICE kernels that take most of the step, by the names rocprofv3's kernel trace gives them (profiles/
+        # r04_bench_b256_kernel_stats.csv: Calls / traced steps = launches, AverageNs = avg_ms): SURVEY 8(d) bytes and flops
+        # per launch and the fraction of the roof each sits under, so that the family figure above can be recomputed name by name
+        top = sorted(ktable.items(), key=lambda kv: -kv[1]["ms"])[:5]
+        rows5 = []
+        for kn, v in top:
+            ksec = v["ms"] * 1e-3
+            fh, fm = v["bytes_8d"] / ksec / 1e9 / PEAK_HBM_GBS, v["flops"] / ksec / 1e12 / PEAK_BF16_TFLOPS
+            rows5.append(dict(name=kn, launches=v["launches"],
+                              avg_ms=round(v["ms"] / v["launches"], 4), ms_per_step=round(v["ms"], 3),
+                              algorithmic_GB_per_launch=round(v["bytes_8d"] / v["launches"] / 1e9, 3),
+                              as_built_GB_per_launch=round(v["bytes"] / v["launches"] / 1e9, 3),
+                              GFLOP_per_launch=round(v["flops"] / v["launches"] / 1e9, 1),
+                              bound="hbm" if fh >= fm else "mfma", frac=round(max(fh, fm), 4), frac_hbm=round(fh, 4), frac_mfma=round(fm, 4)))
+        roof["kernels"] = rows5
         K.DETAIL[0] = True
         with K.profile() as prof3:
             step()

@@ -28,12 +28,17 @@ extern "C" {
 #define MAAI_BF16 0
 #define MAAI_F32 1
 
-#define MAAI_ABI_VERSION 5
+#define MAAI_ABI_VERSION 6
 
 int maai_abi_version(void);
 const char* maai_last_error(void);
 /* number of visible HIP devices, or -1 (used by the host side to fail loudly) */
 int maai_device_count(void);
+/* Kernel-name notes (measurement only): after maai_kernel_names(1), maai_last_kernel_name() returns the name of the device
+ * kernel the calling thread's latest compute call launched last, as rocprofv3's kernel trace prints it ("" when the call
+ * launched a kernel that carries no note) — bench.py's roofline.kernels rows are keyed by it.  Returns the previous setting. */
+int maai_kernel_names(int on);
+const char* maai_last_kernel_name(void);
 
 /* ------------------------------------------------------------------------
  * Convolution as implicit GEMM on MFMA.
@@ -211,11 +216,13 @@ int maai_bn_finalize(const double* sums, double count, const float* gamma, const
  * mean | invstd | count per layer): maai_bn_pack_stats turns a rank's fp64 sums over `count` samples into
  * packed[2C+1] = mean[C] | M2[C] = sum (x - mean)^2 | count (bit pattern of an int32); after an all-gather,
  * maai_bn_finalize_gathered merges the `world` rows (row r at gathered + r*row_stride, row_stride >= 2C+1 floats)
- * with Chan's parallel-variance formula in fp64 and produces what maai_bn_finalize produces. */
+ * with Chan's parallel-variance formula in fp64 and produces what maai_bn_finalize produces; count_out (nullable, device)
+ * receives the merged sample count N = sum of the rows' counts — the ranks' batches may differ — for the backward's 1/N
+ * (maai_bn_bwd_coeffs*, count_dev), as nn.SyncBatchNorm uses the summed gathered counts in both passes. */
 int maai_bn_pack_stats(const double* sums, double count, float* packed, int C, void* stream);
 int maai_bn_finalize_gathered(const float* gathered, int world, long long row_stride, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                              float* scale, float* shift, int C, void* stream);
+                              float* scale, float* shift, double* count_out, int C, void* stream);
 /* eval mode: scale/shift from running statistics */
 int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* scale, float* shift, int C, void* stream);
@@ -250,12 +257,14 @@ int maai_bn_act_bwd_reduce(const void* dout, const void* out, const void* y, con
                            long long M, int C, int relu, int dtype, void* stream);
 /* From sums = [S1 = sum dz, S2 = sum dz*(y-mean)] (double, possibly all-reduced) over `count`:
  *   dbeta = S1, dgamma = invstd*S2,
- *   dy = k1*dz - k2 - k3*y,  k1 = gamma*invstd, k3 = k1*invstd^2*S2/count, k2 = k1*S1/count - k3*mean */
+ *   dy = k1*dz - k2 - k3*y,  k1 = gamma*invstd, k3 = k1*invstd^2*S2/count, k2 = k1*S1/count - k3*mean
+ * count_dev (nullable): a device double that overrides `count` (the merged count of maai_bn_finalize_gathered). */
 int maai_bn_bwd_coeffs(const double* sums, double count, const float* gamma, const float* mean, const float* invstd,
-                       float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, void* stream);
+                       float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, const double* count_dev, void* stream);
 /* the same from fp32 sums (the cross-rank all-reduce of SyncBatchNorm's backward travels in fp32) */
 int maai_bn_bwd_coeffs_f32(const float* sums, double count, const float* gamma, const float* mean, const float* invstd,
-                           float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, void* stream);
+                           float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C, const double* count_dev,
+                           void* stream);
 /* backward pass 2: dz = dout*(out>0); dy = k1[c]*dz - k2[c] - k3[c]*y; optional
  * dz_out (gradient of the residual input) written too. k* nullable -> dy = dz. */
 int maai_bn_act_bwd_apply(const void* dout, const void* out, const void* y, const float* k1, const float* k2,
@@ -309,6 +318,25 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
                               int normalize, void* stream);
 
 /* ------------------------------------------------------------------------
+ * BatchNorm-backward folded through a channel-expanding pointwise convolution (csrc/fold.hip): y = x W^T followed by
+ * training-mode BatchNorm — conv3 + bn3 of the reference's Bottleneck (SimCLR/ResNet/resnet.py:118-119).  With
+ * G1 = g^T x (maai_conv2d_wgrad on the UN-normalised gradient g), Gram = x^T x and sx = colsum(x):
+ *   maai_fold_s2:      s2[c] = sum_k W[c,k] G1[c,k] - mean[c] s1[c]                 (= sum g*(y - mean) without reading y)
+ *   maai_fold_dw:      dw[c,k] = k1[c] G1[c,k] - k2[c] sx[k] - k3[c] (W Gram)[c,k]  (= (k1*g - k2 - k3*y)^T x)
+ *   maai_fold_dgrad_w: wf[k][c] = bf16(k1[c] W[c,k]), tn[k][j] = bf16(-(W^T diag(k3) W)[j,k]), cn[k] = -(k2 W)[k] - comp[k], so that
+ *                      dx = g wf^T + x tn^T + cn                                    (= (k1*g - k2 - k3*y) W)
+ *                      comp[k] = (s1 . (wf[k] - exact) + sx . (tn[k] - exact)) / count: the pixel mean of what the bf16 rounding
+ *                      of the folded weights adds to dx[:, k] (s1 = sum g, sx = colsum x over `count` pixels) — taken out of the
+ *                      constant so that this rounding error is zero-mean over the pixels; scratch: Cin floats.
+ * w: the bf16 kernel-layout weights [Cout][Cin]; g1, gram, dw fp32; s1, s2, sx fp64; k1..k3 as maai_bn_bwd_coeffs gives them.
+ * ------------------------------------------------------------------------ */
+int maai_fold_s2(const void* w, const float* g1, const double* s1, const float* mean, double* s2, int Cout, int Cin, void* stream);
+int maai_fold_dw(const void* w, const float* g1, const float* gram, const double* sx, const float* k1, const float* k2,
+                 const float* k3, float* dw, int Cout, int Cin, void* stream);
+int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const float* k3, const double* s1, const double* sx,
+                      double count, void* wf, void* tn, float* cn, float* scratch, int Cout, int Cin, void* stream);
+
+/* ------------------------------------------------------------------------
  * Comm helper: one-shot direct all-gather over the xGMI mesh (symmetric buffers, peer-to-peer stores) — the
  * transport-level replacement of Objective._cross_replica_concat's dist.all_gather + torch.cat (SimCLR/Objective.py:
  * 102-114) for the [B,128] embeddings; the RCCL path (torch.distributed) remains the default.  Setup: every rank
@@ -316,8 +344,12 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
  * by any means (the callers use their process group) and attaches the handles it receives.  maai_comm_allgather then
  * writes this rank's message into its slot of every peer's buffer (8-byte {epoch, payload} granules, one system-scope
  * store each: the data is the flag) and gathers dst[world][bytes] from its own buffer, all in one kernel on `stream`.
- * A rank may run at most one gather ahead of any other rank (two epoch parities).  Spins are bounded; maai_comm_status
- * returns the epoch of the first gather that gave up on a peer (0 = none; synchronises with the device).
+ * A rank may run at most one gather ahead of any other rank (two epoch parities).  The buffers are fine-grained device
+ * memory (maai_comm_create fails where that is unavailable: no coarse-grained fallback).  A sweep waits for a granule at most
+ * MAAI_P2P_TIMEOUT_MS of wall-clock time (default 120 000); a gather that gives up delivers quiet NaNs for the granules it
+ * did not get (never stale data) and sets a host-visible status word to its epoch: maai_comm_poll returns that word without
+ * synchronising, maai_comm_status after hipDeviceSynchronize, and maai_comm_allgather refuses (MAAI_ERR_LAUNCH) once it is
+ * set — the ranks' epochs have diverged and the communicator is dead.
  * ------------------------------------------------------------------------ */
 typedef struct maai_comm maai_comm;
 int maai_comm_create(int rank, int world, long long max_bytes, maai_comm** out);
@@ -325,6 +357,7 @@ int maai_comm_handle(maai_comm* c, void* handle64);
 int maai_comm_attach(maai_comm* c, int peer, const void* handle64);
 int maai_comm_allgather(maai_comm* c, const void* src, long long bytes, void* dst, void* stream);
 int maai_comm_status(maai_comm* c, unsigned* status);
+int maai_comm_poll(maai_comm* c, unsigned* status);
 int maai_comm_destroy(maai_comm* c);
 
 /* ------------------------------------------------------------------------

@@ -106,6 +106,7 @@ extern "C" int maai_reduce_partials(const float* partial, long long rows, int C2
     if (slices < 1) slices = 1;
     const long long rpb = (rows + slices - 1) / slices;
     dim3 grid(gx, (unsigned)((rows + rpb - 1) / rpb));
+    MAAI_NOTE_KERNEL(reduce_partials_kernel);
     hipLaunchKernelGGL(reduce_partials_kernel, grid, dim3(256), 0, st, partial, rows, C2, sums, rpb, L);
   } else {
     long long slices = (rows + 255) / 256;
@@ -186,7 +187,7 @@ extern "C" int maai_bn_pack_stats(const double* sums, double count, float* packe
 __global__ void bn_finalize_gathered_kernel(const float* __restrict__ g, int world, long long row_stride,
                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                             float* running_var, float momentum, float eps, float* mean_o, float* invstd_o,
-                                            float* scale_o, float* shift_o, int C) {
+                                            float* scale_o, float* shift_o, double* count_o, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double N = 0.0, S = 0.0;
@@ -195,6 +196,7 @@ __global__ void bn_finalize_gathered_kernel(const float* __restrict__ g, int wor
     N += n;
     S += n * (double)g[r * row_stride + c];
   }
+  if (count_o && c == 0) *count_o = N;   // the merged sample count: what the backward's 1/N uses (the ranks' batches may differ)
   const double mean = S / N;
   double M2 = 0.0;
   for (int r = 0; r < world; ++r) {
@@ -219,10 +221,12 @@ __global__ void bn_finalize_gathered_kernel(const float* __restrict__ g, int wor
 
 extern "C" int maai_bn_finalize_gathered(const float* gathered, int world, long long row_stride, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                         float* mean, float* invstd, float* scale, float* shift, int C, void* stream) {
+                                         float* mean, float* invstd, float* scale, float* shift, double* count_out, int C,
+                                         void* stream) {
   MAAI_CHECK_ARG(gathered && scale && shift && C > 0 && world > 0 && row_stride >= 2LL * C + 1, "bn_finalize_gathered: bad arguments");
   hipLaunchKernelGGL(bn_finalize_gathered_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     gathered, world, row_stride, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C);
+                     gathered, world, row_stride, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                     count_out, C);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -359,12 +363,16 @@ extern "C" int maai_bn_act_fwd_mask(const void* y, const float* scale, const flo
   MAAI_CHECK_ARG(C % E == 0, "bn_act_fwd: C must be a multiple of 8 (bf16) / 4 (f32)");
   const long long nchunks = M * (C / E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16)
+  if (dtype == MAAI_BF16) {
+    MAAI_NOTE_KERNEL(bn_act_fwd_kernel<bf16_t>);
     hipLaunchKernelGGL(bn_act_fwd_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)y, scale,
                        shift, (const bf16_t*)residual, (bf16_t*)out, mask_bits, nchunks, C / E, relu);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(bn_act_fwd_kernel<float>);
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)y, scale,
                        shift, (const float*)residual, (float*)out, nullptr, nchunks, C / E, relu);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -469,22 +477,27 @@ extern "C" int maai_bn_act_bwd_reduce(const void* dout, const void* out, const v
   MAAI_CHECK_ARG(256 % cs == 0, "bn_act_bwd_reduce: C/vector must divide 256 or be a multiple of it");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)rows, ny);
-  if (dtype == MAAI_BF16)
+  if (dtype == MAAI_BF16) {
+    MAAI_NOTE_KERNEL(bn_bwd_reduce_kernel<bf16_t>);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
                        (const bf16_t*)y, mean, partial, M, C, cs, rpb, relu);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(bn_bwd_reduce_kernel<float>);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out,
                        (const float*)y, mean, partial, M, C, cs, rpb, relu);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
 
 template <typename TS>   // TS: double (local / fp64-reduced sums) or float (the fp32 cross-rank exchange)
-__global__ void bn_bwd_coeffs_kernel(const TS* __restrict__ sums, double count, const float* gamma, const float* mean,
-                                     const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3,
-                                     int C) {
+__global__ void bn_bwd_coeffs_kernel(const TS* __restrict__ sums, double count, const double* __restrict__ count_dev,
+                                     const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                     float* k1, float* k2, float* k3, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = *count_dev;   // (SyncBatchNorm: the merged count of maai_bn_finalize_gathered, never read back by the host)
   const double S1 = sums[c], S2 = sums[C + c];
   const double is = invstd[c], g = gamma ? gamma[c] : 1.0, mu = mean[c];
   if (dbeta) dbeta[c] = (float)S1;
@@ -498,20 +511,20 @@ __global__ void bn_bwd_coeffs_kernel(const TS* __restrict__ sums, double count, 
 
 extern "C" int maai_bn_bwd_coeffs(const double* sums, double count, const float* gamma, const float* mean,
                                   const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
-                                  void* stream) {
-  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && count > 0, "bn_bwd_coeffs: bad arguments");
+                                  const double* count_dev, void* stream) {
+  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && (count > 0 || count_dev), "bn_bwd_coeffs: bad arguments");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel<double>, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
-                     count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
+                     count, count_dev, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
 
 extern "C" int maai_bn_bwd_coeffs_f32(const float* sums, double count, const float* gamma, const float* mean,
                                       const float* invstd, float* dgamma, float* dbeta, float* k1, float* k2, float* k3, int C,
-                                      void* stream) {
-  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && count > 0, "bn_bwd_coeffs_f32: bad arguments");
+                                      const double* count_dev, void* stream) {
+  MAAI_CHECK_ARG(sums && mean && invstd && k1 && k2 && k3 && C > 0 && (count > 0 || count_dev), "bn_bwd_coeffs_f32: bad arguments");
   hipLaunchKernelGGL(bn_bwd_coeffs_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), sums,
-                     count, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
+                     count, count_dev, gamma, mean, invstd, dgamma, dbeta, k1, k2, k3, C);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -572,12 +585,16 @@ extern "C" int maai_bn_act_bwd_apply(const void* dout, const void* out, const vo
   MAAI_CHECK_ARG(C % E == 0, "bn_act_bwd_apply: C must be a multiple of 8 (bf16) / 4 (f32)");
   const long long nchunks = M * (C / E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16)
+  if (dtype == MAAI_BF16) {
+    MAAI_NOTE_KERNEL(bn_bwd_apply_kernel<bf16_t>);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)dout,
                        (const bf16_t*)out, (const bf16_t*)y, k1, k2, k3, (bf16_t*)dy, (bf16_t*)dz_out, nchunks, C / E, relu);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(bn_bwd_apply_kernel<float>);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)dout,
                        (const float*)out, (const float*)y, k1, k2, k3, (float*)dy, (float*)dz_out, nchunks, C / E, relu);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -592,12 +609,16 @@ extern "C" int maai_bn_act_fwd2(const void* y, const float* scale, const float* 
   MAAI_CHECK_ARG(C % E == 0, "bn_act_fwd2: C must be a multiple of 8 (bf16) / 4 (f32)");
   const long long nchunks = M * (C / E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16)
+  if (dtype == MAAI_BF16) {
+    MAAI_NOTE_KERNEL(bn_act_fwd2_kernel<bf16_t>);
     hipLaunchKernelGGL(bn_act_fwd2_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)y, scale,
                        shift, (const bf16_t*)y2, scale2, shift2, (bf16_t*)out, mask_bits, nchunks, C / E, relu);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(bn_act_fwd2_kernel<float>);
     hipLaunchKernelGGL(bn_act_fwd2_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)y, scale,
                        shift, (const float*)y2, scale2, shift2, (float*)out, nullptr, nchunks, C / E, relu);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -643,12 +664,16 @@ extern "C" int maai_bn_act_bwd_apply2(const void* dz, const void* y, const float
   MAAI_CHECK_ARG(C % E == 0, "bn_act_bwd_apply2: C must be a multiple of 8 (bf16) / 4 (f32)");
   const long long nchunks = M * (C / E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16)
+  if (dtype == MAAI_BF16) {
+    MAAI_NOTE_KERNEL(bn_bwd_apply2_kernel<bf16_t>);
     hipLaunchKernelGGL(bn_bwd_apply2_kernel<bf16_t>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const bf16_t*)dz,
                        (const bf16_t*)y, k1, k2, k3, (const bf16_t*)y2, k1b, k2b, k3b, (bf16_t*)dy, (bf16_t*)dy2, nchunks, C / E);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(bn_bwd_apply2_kernel<float>);
     hipLaunchKernelGGL(bn_bwd_apply2_kernel<float>, dim3(stream_grid(nchunks)), dim3(256), 0, st, (const float*)dz,
                        (const float*)y, k1, k2, k3, (const float*)y2, k1b, k2b, k3b, (float*)dy, (float*)dy2, nchunks, C / E);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

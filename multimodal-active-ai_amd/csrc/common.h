@@ -15,6 +15,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define MAAI_ERR_UNSUPPORTED 3
 
 extern "C" void maai_set_error(const char* msg);
+// Kernel-name notes for bench.py's per-kernel roofline rows (maai_kernel_names(1) switches them on): every launcher of a
+// hot kernel calls MAAI_NOTE_KERNEL(kernel<...>) right before its launch; maai_last_kernel_name() then returns that
+// instantiation's name as rocprofv3's kernel trace prints it (the demangled symbol, without "void" and the argument list).
+extern "C" void maai_note_kernel(const void* host_function);
+#define MAAI_NOTE_KERNEL(...) maai_note_kernel(reinterpret_cast<const void*>(&__VA_ARGS__))
 
 // also clears any stale (sticky) runtime error so that MAAI_CHECK_LAUNCH reports only our own launch
 #define MAAI_CHECK_ARG(cond, msg)        \

@@ -329,9 +329,11 @@ extern "C" int maai_conv_bwd3(const void* g, const void* y3, const void* y2, con
   static int attr[2][64] = {{0}};
   if (accumulate) {
     maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<true>), lds, attr[0]);
+    MAAI_NOTE_KERNEL(conv_bwd3_kernel<true>);
     hipLaunchKernelGGL((conv_bwd3_kernel<true>), dim3((unsigned)grid), dim3(256), lds, st, a);
   } else {
     maai_ensure_lds(reinterpret_cast<const void*>(&conv_bwd3_kernel<false>), lds, attr[1]);
+    MAAI_NOTE_KERNEL(conv_bwd3_kernel<false>);
     hipLaunchKernelGGL((conv_bwd3_kernel<false>), dim3((unsigned)grid), dim3(256), lds, st, a);
   }
   MAAI_CHECK_LAUNCH();

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(64 * C64_NW, 1) void conv_c64_kernel(ConvArgs a) {
       prem = (1u << C64_NCH) - 1u;
       return;
     }
-    const bool cok0 = ox0 - 1 + lx >= 0, cok1 = ox0 + 7 + lx < W;
+    // (both bounds on both column groups: a ragged last patch column — W % 16 in 1..6 — ends inside group 0)
+    const bool cok0 = (unsigned)(ox0 - 1 + lx) < (unsigned)W, cok1 = (unsigned)(ox0 + 7 + lx) < (unsigned)W;
     unsigned m = 0;
 #pragma unroll
     for (int hy = 0; hy < C64_HR; ++hy) {
@@ -452,6 +453,7 @@ static int launch_c64(const ConvArgs& a, hipStream_t st) {
   static int attr[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_c64_kernel<XF, EMODE>), lds, attr);
   const int grid = maai_conv_c64_rows(a) / C64_NW;
+  MAAI_NOTE_KERNEL(conv_c64_kernel<XF, EMODE>);
   hipLaunchKernelGGL((conv_c64_kernel<XF, EMODE>), dim3((unsigned)grid), dim3(64 * C64_NW), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

@@ -326,6 +326,7 @@ static int launch_chain(ConvArgs a, hipStream_t st) {
   a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_chain_kernel<KC1, DIST, PROJ, BITS, KEEPY>), lds, attr_lds);
+  MAAI_NOTE_KERNEL(conv_chain_kernel<KC1, DIST, PROJ, BITS, KEEPY>);
   hipLaunchKernelGGL((conv_chain_kernel<KC1, DIST, PROJ, BITS, KEEPY>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

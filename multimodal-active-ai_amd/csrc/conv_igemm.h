@@ -857,6 +857,7 @@ static int launch_conv_p(const ConvArgs& a, hipStream_t st) {
   static int attr_lds[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>), lds, attr_lds);
   const long long grid = (long long)a.nMB * a.nNB;
+  MAAI_NOTE_KERNEL(conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>);
   hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, NSTAGE, EMODE, PW, HALO, AXF, XF>), dim3((unsigned)grid), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
   issue_kind(std::integral_constant<int, 1>(), 1);
   pp_wait_vm<2 * NAI + NBI>();   // elements 3, 4, 5 — A1(0), A0(1), B0(1) — may stay in flight (KT >= 2: they all exist)
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if (wid >= 4) __builtin_amdgcn_s_barrier();   // (halves by wave id: waves 4-7 are the second wave of every SIMD, whatever the wave grid)
 
   // the wait of a phase in the last two tiles: elements g+3 .. g+5 that exist may stay in flight
   auto tail_wait = [&](int g) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
   tile(std::integral_constant<int, 0>(), std::false_type(), kt);
   if (kt + 1 < KT) tile(std::integral_constant<int, 1>(), std::false_type(), kt + 1);
   if (kt + 2 < KT) tile(std::integral_constant<int, 0>(), std::false_type(), kt + 2);
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // H0 catches up with H1's extra barrier
+  if (wid < 4) __builtin_amdgcn_s_barrier();   // H0 catches up with H1's extra barrier
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();                             // the operand buffers are free: the C areas reuse them
 
@@ -536,6 +536,7 @@ static int launch_pp(ConvArgs a, hipStream_t st) {
   a.nNB = a.Cout / BN;
   static int attr_lds[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_pp_kernel<WGM, WGN, EMODE>), lds, attr_lds);
+  MAAI_NOTE_KERNEL(conv_pp_kernel<WGM, WGN, EMODE>);
   hipLaunchKernelGGL((conv_pp_kernel<WGM, WGN, EMODE>), dim3((unsigned)(a.nMB * a.nNB)), dim3(512), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

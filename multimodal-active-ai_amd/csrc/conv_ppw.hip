@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(PpwArgs a) {
   issue_kind(std::integral_constant<int, 1>(), 1);
   pw_wait_vm<6>();
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if (wid >= 4) __builtin_amdgcn_s_barrier();   // (halves by wave id: waves 4-7 are the second wave of every SIMD, whatever the wave grid)
 
   auto tail_wait = [&](int g) {
     int allowed = 0;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pp_kernel(PpwArgs a) {
   tile(std::integral_constant<int, 0>(), std::false_type(), kt);
   if (kt + 1 < KT) tile(std::integral_constant<int, 1>(), std::false_type(), kt + 1);
   if (kt + 2 < KT) tile(std::integral_constant<int, 0>(), std::false_type(), kt + 2);
-  if (wr == 0) __builtin_amdgcn_s_barrier();
+  if (wid < 4) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: fp32 atomics; C layout row (co) = 4*fg + r, column (tap, ci) = li ----
 #pragma unroll
@@ -327,6 +327,7 @@ int maai_wgrad_pp_launch(PpwArgs a, hipStream_t st, int target) {
   constexpr int lds = 131072;
   static int attr[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_pp_kernel), lds, attr);
+  MAAI_NOTE_KERNEL(wgrad_pp_kernel);
   hipLaunchKernelGGL(wgrad_pp_kernel, dim3((unsigned)(tiles * ny8)), dim3(512), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

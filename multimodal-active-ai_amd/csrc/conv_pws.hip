@@ -345,6 +345,7 @@ static int launch_pws(ConvArgs a, hipStream_t st) {
   a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), lds, attr_lds);
+  MAAI_NOTE_KERNEL(conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>);
   hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

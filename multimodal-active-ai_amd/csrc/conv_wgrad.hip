@@ -459,10 +459,14 @@ static int launch_wgrad_ring(WgradArgs a, hipStream_t st, int target) {
   static int attr_a[64] = {0}, attr_b[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), lds, attr_a);
   maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), lds, attr_b);
-  if (a.xs)
+  if (a.xs) {
+    MAAI_NOTE_KERNEL(wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>);
     hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN, true>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>);
     hipLaunchKernelGGL((wgrad_ring_kernel<BCO, BCN, NWM, NWN, false>), dim3((unsigned)(tiles * ny8)), dim3(NT), lds, st, a);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -769,17 +773,21 @@ static int launch_wgrad_patch(const WgradArgs& w, hipStream_t st, int target) {
   if (a.xs) {
     if (db) {
       maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true, true>), lds, attr[0]);
+      MAAI_NOTE_KERNEL(wgrad3x3_patch_kernel<true, true>);
       hipLaunchKernelGGL((wgrad3x3_patch_kernel<true, true>), grid, dim3(384), lds, st, a);
     } else {
       maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<true, false>), lds, attr[1]);
+      MAAI_NOTE_KERNEL(wgrad3x3_patch_kernel<true, false>);
       hipLaunchKernelGGL((wgrad3x3_patch_kernel<true, false>), grid, dim3(384), lds, st, a);
     }
   } else {
     if (db) {
       maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false, true>), lds, attr[2]);
+      MAAI_NOTE_KERNEL(wgrad3x3_patch_kernel<false, true>);
       hipLaunchKernelGGL((wgrad3x3_patch_kernel<false, true>), grid, dim3(384), lds, st, a);
     } else {
       maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_patch_kernel<false, false>), lds, attr[3]);
+      MAAI_NOTE_KERNEL(wgrad3x3_patch_kernel<false, false>);
       hipLaunchKernelGGL((wgrad3x3_patch_kernel<false, false>), grid, dim3(384), lds, st, a);
     }
   }
@@ -823,10 +831,14 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
   static int attr_a[64] = {0}, attr_b[64] = {0};
   maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, false>), lds, attr_a);
   maai_ensure_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, BCO, BCI, true>), lds, attr_b);
-  if (a.xs)
+  if (a.xs) {
+    MAAI_NOTE_KERNEL(wgrad_kernel<T, BCO, BCI, true>);
     hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, true>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
-  else
+  }
+  else {
+    MAAI_NOTE_KERNEL(wgrad_kernel<T, BCO, BCI, false>);
     hipLaunchKernelGGL((wgrad_kernel<T, BCO, BCI, false>), dim3((unsigned)tiles, ny), dim3(256), lds, st, a);
+  }
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

@@ -43,6 +43,8 @@ SIGNATURES = {
     "maai_adam_step_multi": (c_i, [c_p, c_p, c_p, c_i, C.c_double, C.c_double, C.c_double, C.c_double, c_i, C.c_float, c_p]),
     "maai_last_error": (C.c_char_p, []),
     "maai_device_count": (c_i, []),
+    "maai_kernel_names": (c_i, [c_i]),
+    "maai_last_kernel_name": (C.c_char_p, []),
     "maai_conv2d_igemm": (c_i, [_P_DESC, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_conv2d_stats_rows": (c_ll, [_P_DESC, c_i]),
     "maai_conv2d_kernel_family": (c_i, [_P_DESC, c_i]),
@@ -63,10 +65,10 @@ SIGNATURES = {
     "maai_bn_act_bwd_apply2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_p]),
     "maai_bn_bwd_rows": (c_ll, [c_ll, c_i, c_i]),
     "maai_bn_act_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
-    "maai_bn_bwd_coeffs": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
-    "maai_bn_bwd_coeffs_f32": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_bwd_coeffs": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "maai_bn_bwd_coeffs_f32": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "maai_bn_pack_stats": (c_i, [c_p, c_d, c_p, c_i, c_p]),
-    "maai_bn_finalize_gathered": (c_i, [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_finalize_gathered": (c_i, [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "maai_bn_act_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_pack_views_u8": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "maai_stem_unroll_nchw_f32": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p]),
@@ -85,11 +87,15 @@ SIGNATURES = {
     "maai_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_ll, c_d, c_d, c_d, c_d, c_i, c_f, c_p]),
     "maai_sgd_step": (c_i, [c_p, c_p, c_p, c_ll, c_f, c_f, c_f, c_i, c_p]),
     "maai_sgd_step_multi": (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
+    "maai_fold_s2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maai_fold_dw": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_comm_create": (c_i, [c_i, c_i, c_ll, c_p]),
     "maai_comm_handle": (c_i, [c_p, c_p]),
     "maai_comm_attach": (c_i, [c_p, c_i, c_p]),
     "maai_comm_allgather": (c_i, [c_p, c_p, c_ll, c_p, c_p]),
     "maai_comm_status": (c_i, [c_p, c_p]),
+    "maai_comm_poll": (c_i, [c_p, c_p]),
     "maai_comm_destroy": (c_i, [c_p]),
     "maai_multi_sqnorm": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     "maai_larc_scale": (c_i, [c_p, c_p, c_p, c_i, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
@@ -107,7 +113,7 @@ class MaaiError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
+ABI_VERSION = 6   # == MAAI_ABI_VERSION of include/maai_hip.h (checked in tests/test_host.py); bumped with every signature change
 
 
 def _autobuild():

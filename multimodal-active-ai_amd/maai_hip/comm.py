@@ -66,15 +66,30 @@ class P2PGather(object):
             raise MaaiError("P2PGather.gather: %d bytes exceed the %d the buffers were created for" % (nbytes, self.max_bytes))
         if out is None:
             out = torch.empty((self.world * z.shape[0],) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+        self.check()
         _lib.check(_lib.lib().maai_comm_allgather(self._h, C.c_void_p(z.data_ptr()), nbytes, C.c_void_p(out.data_ptr()),
                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "maai_comm_allgather")
         return out
 
     def status(self):
-        """0, or the epoch of the first gather that gave up waiting for a peer (synchronises with the device)."""
+        """0, or the epoch of the latest gather that gave up waiting for a peer (synchronises with the device)."""
         s = C.c_uint(0)
         _lib.check(_lib.lib().maai_comm_status(self._h, C.byref(s)), "maai_comm_status")
         return int(s.value)
+
+    def poll(self):
+        """The same word without synchronising: what the gathers that have FINISHED so far reported."""
+        s = C.c_uint(0)
+        _lib.check(_lib.lib().maai_comm_poll(self._h, C.byref(s)), "maai_comm_poll")
+        return int(s.value)
+
+    def check(self):
+        """Raise if a finished gather timed out on a peer (its output was NaN-poisoned, the ranks' epochs have diverged).
+        Called before every gather and whenever ``maai_hip.dist`` hands a gathered tensor to the loss."""
+        e = self.poll()
+        if e:
+            raise MaaiError("P2PGather: gather %d gave up waiting for a peer after MAAI_P2P_TIMEOUT_MS (default 120 s); its "
+                            "output was poisoned with NaN and this communicator cannot be used again" % e)
 
     def close(self):
         if self._h:

@@ -80,7 +80,7 @@ def prefetch_embedding(h, normalize_fn, world_size=None, group=None):
                 p2p = comm.p2p_gather_for(z.numel() * 4, group)   # MAAI_P2P_GATHER=1: one-shot direct all-gather over xGMI
             if p2p is not None:
                 p2p.gather(z.contiguous(), out)
-                work = _Done()
+                work = _Done(p2p)
                 STATS["p2p_gathers"] = STATS.get("p2p_gathers", 0) + 1
             else:
                 work = dist.all_gather_into_tensor(out, z, group=group, async_op=True)
@@ -102,7 +102,7 @@ def take_prefetched(h, world_size):
         if entry is not None and key == k and entry[5] == world_size and _alive(entry, h):
             work, z, inv, out, side = entry[:5]
             STATS["prefetch_hits"] += 1
-            work.wait()                         # orders the current stream behind the collective
+            work.wait()                         # orders the current stream behind the collective (direct transport: raises if a gather timed out)
             if side is not None:
                 cur = torch.cuda.current_stream(z.device)
                 cur.wait_stream(side)           # ... and behind the normalisation that fed it
@@ -267,9 +267,15 @@ class GradReducer(object):
 
 
 class _Done(object):
-    """stands in for the Work handle of a collective that was enqueued as an ordinary kernel on the side stream"""
+    """stands in for the Work handle of a collective that was enqueued as an ordinary kernel on the side stream; with the
+    direct transport ``wait`` also checks (without synchronising) that no finished gather gave up on a peer"""
+
+    def __init__(self, p2p=None):
+        self.p2p = p2p
 
     def wait(self):
+        if self.p2p is not None:
+            self.p2p.check()
         return True
 
 

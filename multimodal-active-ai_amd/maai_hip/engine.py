@@ -217,7 +217,7 @@ def w_linear_dgrad(param, dtype, nhwc_from=None):
 # ----------------------------------------------------------------------------
 class _Rec(object):
     __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
-                 "count", "world", "training", "form", "in_hw", "fused", "shift", "bits")
+                 "count", "world", "training", "form", "in_hw", "fused", "shift", "bits", "fold")
 
 
 # Pointwise expanding convolutions with few input channels (conv3 / downsample of the first stages) are HBM-bound
@@ -638,7 +638,6 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         if world > 1:
             # one fp32 row per rank: mean | M2 | count, merged after the all-gather (Chan) — nn.SyncBatchNorm's protocol
             gathered = yield ("gather", K.bn_pack_stats(sums, count))
-            count *= world   # (every rank runs the same per-GPU batch: what the backward's 1/count uses)
         mom = bn.momentum
         if bn.track_running_stats and bn.running_mean is not None:
             if mom is None:
@@ -651,7 +650,9 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             rm = rv = None
             mom = 0.0
         if gathered is not None:
-            mean, invstd, scale, shift = K.bn_finalize_gathered(gathered, bn.weight, bn.bias, rm, rv, mom, bn.eps)
+            # (count: the MERGED sample count as a device scalar — the ranks' batches may differ, e.g. a last batch without
+            #  drop_last — which the backward's 1/N takes as is: torch.nn.SyncBatchNorm uses the summed counts in both passes)
+            mean, invstd, scale, shift, count = K.bn_finalize_gathered(gathered, bn.weight, bn.bias, rm, rv, mom, bn.eps)
         else:
             mean, invstd, scale, shift = K.bn_finalize(sums, count, bn.weight, bn.bias, rm, rv, mom, bn.eps)
     else:
@@ -676,7 +677,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused, r.shift, r.bits = (x.shape[1], x.shape[2]), True, shift, None
+        r.in_hw, r.fused, r.shift, r.bits, r.fold = (x.shape[1], x.shape[2]), True, shift, None, None
         return out, r
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
@@ -701,7 +702,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
         r.in_hw = (x.shape[1], x.shape[2])
-        r.fused, r.shift, r.bits = False, shift, None
+        r.fused, r.shift, r.bits, r.fold = False, shift, None, None
         return lz, r
     elif branch is not None:
         if residual is not None:
@@ -720,7 +721,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
-    r.fused, r.shift, r.bits = False, shift, bits
+    r.fused, r.shift, r.bits, r.fold = False, shift, bits, None
     return ((y, scale, shift) if defer else out), r
 
 
@@ -756,7 +757,7 @@ def axf_applies(rec, dz, below, need_dx=True):
 
 
 def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None, axf=None,
-               sum_increment=False):
+               sum_increment=False, wq_dgrad=None):
     """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]; with ``relu_mask`` (= x,
     a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue.  ``below`` = the record of
     the unit whose output x is: the mask is then that unit's, and where every pixel of dx is written exactly once
@@ -799,7 +800,8 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
             gh, gw = (ih - a + stride - 1) // stride, (iw - b + stride - 1) // stride
             if gh <= 0 or gw <= 0:
                 continue
-            launches.append((w_dgrad(weight, dtype, khs, kws), pad_h, pad_w, (gh, gw), (a, b)))
+            # (``wq_dgrad``: the pointwise layer's [Cin,1,1,Cout] weights as the caller built them — the folded unit's k1*W)
+            launches.append((wq_dgrad if wq_dgrad is not None else w_dgrad(weight, dtype, khs, kws), pad_h, pad_w, (gh, gw), (a, b)))
     if axf is not None and not (fuse and len(launches) == 1):
         raise MaaiError("conv_dgrad: the transformed operand needs a single fused pointwise launch")
     if not fuse:
@@ -832,6 +834,58 @@ def _grad_to_reference(rec, dw):
     return g.contiguous()
 
 
+# BatchNorm-backward FOLDED through a channel-expanding pointwise convolution (conv3 of the bottlenecks, resnet.py:118-119).
+# For y = x W^T (x: [M, Cin] the unit's input, W: [Cout, Cin]) followed by training-mode BatchNorm, the backward
+#     dy = k1*g - k2 - k3*y,   S1 = sum g,  S2 = sum g*(y - mean)         (g = gradient of the BatchNorm's output)
+# needs y only through LINEAR functions of y = x W^T, which can be moved onto the [Cout, Cin] / [Cin, Cin] side:
+#     G1 = g^T x                 (a weight-gradient launch on the UN-normalised gradient: no dependence on k1..k3)
+#     S2 = rowsum(W * G1) - mean * S1
+#     dW = k1 * G1 - k2 (x) colsum(x) - k3 * (W Gram),   Gram = x^T x
+#     dx = g (k1 * W) - x (W^T diag(k3) W) - k2 W
+# so neither the BatchNorm-backward apply pass (read g, read y, write dy: three Cout-wide tensors) nor the read of y by the
+# epilogue that reduces S2 exists, and y itself is not needed by the backward pass at all (4 x fewer channels in x).
+# Arithmetic: exact in real numbers; in bf16 storage y is never rounded (the unfolded path rounds it once), the folded
+# weights k1*W and W^T diag(k3) W are rounded to bf16 once each.  Pinned against the fp64 oracle per block
+# (tests/test_gpu_fold.py) — not bit-identical to the unfolded path.  MAAI_FOLD=0 turns it off.
+_FOLD = {"enabled": os.environ.get("MAAI_FOLD", "1") != "0"}
+
+
+def set_fold(flag):
+    _FOLD["enabled"] = bool(flag)
+
+
+def _fold_applies(rec, dout):
+    if not (_FOLD["enabled"] and rec is not None and dout is not None and dout.dtype == torch.bfloat16 and rec.training and rec.form == "fwd"
+            and rec.k == 1 and rec.stride == 1 and rec.pad == 0 and not rec.fused):
+        return False
+    w = rec.conv.weight
+    if not (w.shape[0] >= 2 * w.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0):
+        return False
+    # (phase 1: the input is a stored tensor — layer 1's conv3 takes a normalise-on-load input and has its own fused backward)
+    return not isinstance(rec.x, K.Lazy)
+
+
+class _Fold(object):
+    __slots__ = ("g1", "s1")
+
+
+def _fold_sums(rec, dout, presums, dtype):
+    """G1 = g^T x and the BatchNorm-backward sums [S1 | S2] (fp64) of a folded unit; G1 is kept on the record for the weight
+    gradient."""
+    w = rec.conv.weight
+    cout, cin = w.shape[0], w.shape[1]
+    f = _Fold()
+    f.g1 = K.conv2d_wgrad(rec.x, dout, 1, 1, 1, 0, 0).reshape(cout, cin)
+    if presums is not None:
+        f.s1 = presums[:cout]
+    else:
+        f.s1 = K.bn_act_bwd_reduce(dout, None, None, None, False)[:cout]
+    wq = w_fwd(w, dtype).reshape(cout, cin)
+    s2 = K.fold_s2(wq, f.g1, f.s1, rec.mean)
+    rec.fold = f
+    return torch.cat([f.s1, s2])
+
+
 def unit_bwd_coeffs(rec, dout, grads, dtype, presums=None):
     """BatchNorm-backward coefficients (k1, k2, k3) of a unit: see ``_unit_bwd_coeffs_gen``."""
     return _drive(_unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums))
@@ -844,6 +898,8 @@ def _unit_bwd_coeffs_gen(rec, dout, grads, dtype, presums=None):
     bn = rec.bn
 
     def reduce(mean):
+        if _fold_applies(rec, dout):
+            return _fold_sums(rec, dout, presums, dtype)
         if presums is not None:
             return presums
         if rec.fused:   # raw conv output never stored: recompute it inside the reduction
@@ -882,6 +938,8 @@ _BWD3 = {"enabled": os.environ.get("MAAI_BWD3", "1") != "0"}
 
 def _bwd3_applies(rec, dout, below, need_dx, dx_out, accumulate, relu_mask, dy):
     w = rec.conv.weight
+    if _fold_applies(rec, dout):   # (a stored-tensor input: the folded backward takes the unit — it reads neither y3 nor writes dz3)
+        return False
     return (_BWD3["enabled"] and dy is None and need_dx and (dx_out is None) == (not accumulate) and relu_mask is None
             and dout.dtype == torch.bfloat16 and tuple(w.shape) == (256, 64, 1, 1) and rec.stride == 1 and rec.pad == 0
             and w.requires_grad and not rec.fused and rec.y is not None and rec.form == "fwd"
@@ -906,6 +964,9 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
                                    _reduce_mean(below), below.scale, below.shift, dx=dx_out if accumulate else None)
         grads[id(rec.conv.weight)] = _grad_to_reference(rec, dw)
         return dx, K.reduce_partials(slab)
+    if dy is None and _fold_applies(rec, dout):
+        k1, k2, k3 = coeffs if coeffs is not None else unit_bwd_coeffs(rec, dout, grads, dtype, presums)
+        return _unit_bwd_folded(rec, dout, grads, dtype, k1, k2, k3, need_dx, dx_out, accumulate, relu_mask, below, sum_increment)
     fused_apply = dy is None and axf_applies(rec, dout, below, need_dx) and not any(
         len(c[1]) == 0 for c in dgrad_classes(rec.k, rec.stride, rec.pad))
     if fused_apply:
@@ -947,6 +1008,44 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         dx, below_sums = conv_dgrad(dy, w, rec.k, rec.stride, rec.pad, rec.in_hw, dtype, out=dx_out, accumulate=accumulate,
                                     relu_mask=relu_mask, below=below, sum_increment=sum_increment)
     return dx, below_sums
+
+
+_ONES = {}
+
+
+def _ones(c, device):
+    key = (c, device)
+    if key not in _ONES:
+        _ONES[key] = torch.ones(c, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+def _unit_bwd_folded(rec, g, grads, dtype, k1, k2, k3, need_dx, dx_out, accumulate, relu_mask, below, sum_increment):
+    """Backward of a folded unit (see ``_FOLD``): ``g`` is the gradient of the BatchNorm's OUTPUT, used as it is by the
+    weight-gradient launch (already run: rec.fold.g1) and by the data gradient; y is not read."""
+    f = rec.fold
+    if f is None:
+        raise MaaiError("unit_bwd: the folded unit's coefficients were taken without its G1")
+    w = rec.conv.weight
+    cout, cin = w.shape[0], w.shape[1]
+    wq = w_fwd(w, dtype).reshape(cout, cin)
+    x = rec.x
+    sx = K.bn_act_bwd_reduce(x, None, None, None, False)     # colsum(x) (fp64; the second half of the vector is unused)
+    if w.requires_grad:
+        gram = K.conv2d_wgrad(x, x, 1, 1, 1, 0, 0).reshape(cin, cin)   # Gram = x^T x: a weight-gradient launch of x against itself
+        dw = K.fold_dw(wq, f.g1, gram, sx, k1, k2, k3)
+        grads[id(w)] = dw.reshape(cout, cin, 1, 1)
+    rec.fold = None
+    if not need_dx:
+        return None, None
+    npix = x.numel() // cin      # (the LOCAL pixel count: s1 and sx are this rank's sums)
+    wf, tn, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix)
+    # dx = g (k1 W) - x (W^T diag(k3) W) - k2 W: the short term first (K = Cin, a pointwise launch whose epilogue adds the
+    # constant and — shortcut units — what is already in dx), then the long one accumulates onto it with the mask and the
+    # BatchNorm-backward sums of the unit below in its epilogue
+    dx0 = K.conv2d_bn_act(x, tn, _ones(cin, g.device), cn, dx_out if accumulate else None, False)
+    return conv_dgrad(g, w, 1, 1, 0, rec.in_hw, dtype, out=dx0, accumulate=True, relu_mask=relu_mask, below=below,
+                      sum_increment=False, wq_dgrad=wf)
 
 
 def relu_mask_grad(dout, out):
@@ -1007,7 +1106,7 @@ def set_recompute(flag, layers=None):
 
 def _lighten(r):
     if r is not None:
-        r.x = r.y = r.out = r.bits = None
+        r.x = r.y = r.out = r.bits = r.fold = None
     return r
 
 
@@ -1138,6 +1237,16 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
             if not kd_fused:
                 dyd, _ = K.bn_act_bwd_apply(dout, None, rd.y, kd[0], kd[1], kd[2], False, True, False)
             d, s = unit_bwd(r3, dout, grads, dtype, below=below3, coeffs=k3)
+        elif r3.fold is not None or rd.fold is not None:
+            # a folded branch needs no apply pass (``_FOLD``): the other one gets the single-tensor pass
+            if rd.fold is None:
+                dyd, _ = K.bn_act_bwd_apply(dout, None, rd.y, kd[0], kd[1], kd[2], False, True, False)
+            if r3.fold is None:
+                dy3, _ = K.bn_act_bwd_apply(dout, None, r3.y, k3[0], k3[1], k3[2], False, True, False)
+                d, s = unit_bwd(r3, None, grads, dtype, below=below3, dy=dy3)
+                del dy3
+            else:
+                d, s = unit_bwd(r3, dout, grads, dtype, below=below3, coeffs=k3)
         else:
             dy3, dyd = K.bn_act_bwd_apply2(dout, r3.y, k3, rd.y, kd)
             d, s = unit_bwd(r3, None, grads, dtype, below=below3, dy=dy3)
@@ -1182,15 +1291,54 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
 # ready() after the head and after every block, so a bucket's all-reduce starts on the side stream while the blocks
 # below are still being differentiated.
 _GRAD_HOOK = [None]
+# The reference builds DistributedDataParallel and immediately unwraps it (Contrastive_Learning.py:418-424): its replicas never
+# exchange gradients and drift apart.  Under the UNCHANGED driver this engine therefore installs the
+# gradient all-reduce by itself: at the first backward that finds an initialised process group of more than one rank (and no
+# hook set by hand) it builds a ``dist.GradReducer`` over the parameters of that autograd node and keeps it for them.
+# MAAI_GRAD_ALLREDUCE = "auto" (default: as described) | "0" (never: the reference's behaviour, replicas drift) | "1" (same as
+# auto, but a missing process group at the first backward of a multi-rank launch — WORLD_SIZE > 1 — is an error).
+_AUTO_REDUCE = {"mode": os.environ.get("MAAI_GRAD_ALLREDUCE", "auto"), "hooks": {}}   # hooks: {ids of the parameters: (reducer, weak refs)}
 
 
 def set_grad_hook(hook):
+    """An object with ready(grads) / finish(grads) (``maai_hip.dist.GradReducer``), or None: back to the automatic rule."""
     _GRAD_HOOK[0] = hook
 
 
-def backbone_bwd(tape, dout, grads, dtype):
-    """``dout``: gradient wrt the layer4 map, NOT yet masked."""
-    hook = _GRAD_HOOK[0]
+def set_grad_allreduce(mode):
+    """"auto" | "0" | "1" — see MAAI_GRAD_ALLREDUCE above."""
+    if str(mode) not in ("auto", "0", "1"):
+        raise ValueError("grad all-reduce mode must be 'auto', '0' or '1'")
+    _AUTO_REDUCE["mode"] = str(mode)
+    _AUTO_REDUCE["hooks"].clear()
+
+
+def _grad_hook_for(params):
+    """The gradient hook of a backward over ``params``: the one set by hand, else the automatic GradReducer (or None)."""
+    if _GRAD_HOOK[0] is not None:
+        return _GRAD_HOOK[0]
+    mode = _AUTO_REDUCE["mode"]
+    if mode == "0":
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        if mode == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise MaaiError("MAAI_GRAD_ALLREDUCE=1 under WORLD_SIZE > 1, but torch.distributed is not initialised at the first backward")
+        return None
+    if dist.get_world_size() < 2:
+        return None
+    key = tuple(id(p) for p in params)
+    hooks = _AUTO_REDUCE["hooks"]
+    hit = hooks.get(key)
+    if hit is None or any(r() is not p for r, p in zip(hit[1], params)):   # (a recycled id belongs to another parameter)
+        from .dist import GradReducer
+        if len(hooks) >= 4:
+            hooks.clear()
+        hit = hooks[key] = (GradReducer(list(params)), [weakref.ref(p) for p in params])
+    return hit[0]
+
+
+def backbone_bwd(tape, dout, grads, dtype, hook=None):
+    """``dout``: gradient wrt the layer4 map, NOT yet masked.  ``hook``: the gradient hook of this backward (``_grad_hook_for``)."""
     last = tape[-1]
     dout = relu_mask_grad(dout, last[4] if last[0] == "ckpt" else (last[3].out if last[0] == "block" else last[1].out))
     sums = None
@@ -1328,11 +1476,11 @@ class _FusedFn(torch.autograd.Function):
         if not ctx.keep:
             raise MaaiError("backward through a forward that ran without gradients")
         grads = {}
-        hook = _GRAD_HOOK[0]
+        hook = _grad_hook_for(ctx.params)
         dfeat = head_bwd(ctx.g, ctx.htape, dz, grads, ctx.dtype)
         if hook is not None:
             hook.ready(grads)
-        backbone_bwd(ctx.tape, dfeat, grads, ctx.dtype)
+        backbone_bwd(ctx.tape, dfeat, grads, ctx.dtype, hook)
         if grads.pop("_side", False):
             torch.cuda.current_stream().wait_stream(_side_stream())
         if hook is not None:
@@ -1356,10 +1504,13 @@ class _BackboneFn(torch.autograd.Function):
         if not ctx.keep:
             raise MaaiError("backward through a forward that ran without gradients")
         grads = {}
+        hook = _grad_hook_for(ctx.params)
         d = K.nchw_to_nhwc(dfeat.contiguous().float(), ctx.cpad, ctx.dtype)
-        backbone_bwd(ctx.tape, d, grads, ctx.dtype)
+        backbone_bwd(ctx.tape, d, grads, ctx.dtype, hook)
         if grads.pop("_side", False):
             torch.cuda.current_stream().wait_stream(_side_stream())
+        if hook is not None:
+            hook.finish(grads)
         ctx.tape = None
         return (None, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
 

@@ -48,24 +48,27 @@ FLOPS_SCALE = [1.0]  # set by the engine around the stem (executed K includes ze
 
 
 class profile(object):
-    """with kernels.profile() as prof: ... ; prof.table() -> {kernel: dict(ms, flops, bytes, launches)}"""
+    """with kernels.profile() as prof: ... ; prof.table() -> {wrapper name: dict(ms, flops, bytes, bytes_8d, launches)};
+    prof.kernel_table() -> the same keyed by the DEVICE kernel's name as rocprofv3's kernel trace prints it (the library
+    notes the kernel each compute call launched: maai_kernel_names / maai_last_kernel_name)."""
 
     def __enter__(self):
         global _PROF
         self.records = []
         _PROF = self.records
+        self._names_were = lib().maai_kernel_names(1)
         return self
 
     def __exit__(self, *a):
         global _PROF
         _PROF = None
+        lib().maai_kernel_names(self._names_were)
         torch.cuda.synchronize()
 
-    def table(self):
-        """bytes = what the launch moves as built (every tensor its epilogue reads or writes); bytes_8d = SURVEY §8(d)'s
-        algorithmic figure for a convolution: its input once + its output once."""
+    def _table(self, key):
         out = {}
-        for name, flops, nbytes, b8d, e0, e1 in self.records:
+        for rec in self.records:
+            name, flops, nbytes, b8d, e0, e1 = rec[key], rec[2], rec[3], rec[4], rec[5], rec[6]
             t = out.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, bytes_8d=0.0, launches=0))
             t["ms"] += e0.elapsed_time(e1)
             t["flops"] += flops
@@ -73,6 +76,19 @@ class profile(object):
             t["bytes_8d"] += b8d
             t["launches"] += 1
         return out
+
+    def table(self):
+        """bytes = what the launch moves as built (every tensor its epilogue reads or writes); bytes_8d = SURVEY §8(d)'s
+        algorithmic figure for a convolution: its input once + its output once."""
+        return self._table(0)
+
+    def kernel_table(self):
+        return self._table(1)
+
+
+def short_kernel_name(name):
+    """the spelling scripts/profile_summary.py gives rocprofv3's names in profiles/*_kernel_stats.csv"""
+    return name.replace("unsigned short", "bf16")
 
 
 class _timed(object):
@@ -90,7 +106,9 @@ class _timed(object):
         if _PROF is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _PROF.append((self.name, self.flops, self.bytes, self.b8d, self.e0, e1))
+            kn = lib().maai_last_kernel_name()
+            kn = short_kernel_name(kn.decode()) if kn else ""
+            _PROF.append((self.name, kn or self.name, self.flops, self.bytes, self.b8d, self.e0, e1))
 
 
 # ----------------------------------------------------------------------------
@@ -587,7 +605,8 @@ def bn_pack_stats(sums, count):
 
 def bn_finalize_gathered(gathered, gamma, beta, running_mean, running_var, momentum, eps):
     """``gathered``: [world, 2C+1] fp32 rows of ``bn_pack_stats`` (any row stride, unit column stride) -> what
-    ``bn_finalize`` returns for the merged statistics (Chan's parallel variance in fp64)."""
+    ``bn_finalize`` returns for the merged statistics (Chan's parallel variance in fp64) + the merged sample count as a
+    device double (the ranks' batches may differ; it is never read back: ``bn_bwd_coeffs`` takes it as is)."""
     _gpu(gamma, beta, running_mean, running_var)
     if not gathered.is_cuda:
         raise MaaiError("the HIP path needs tensors on a HIP device (got %s); there is no CPU fallback" % gathered.device)
@@ -596,10 +615,11 @@ def bn_finalize_gathered(gathered, gamma, beta, running_mean, running_var, momen
     world, c = gathered.shape[0], (gathered.shape[1] - 1) // 2
     dev = gathered.device
     mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    count = torch.empty(1, dtype=torch.float64, device=dev)
     check(lib().maai_bn_finalize_gathered(_p(gathered), world, gathered.stride(0), _p(gamma), _p(beta), _p(running_mean),
                                           _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale),
-                                          _p(shift), c, _stream()), "maai_bn_finalize_gathered")
-    return mean, invstd, scale, shift
+                                          _p(shift), _p(count), c, _stream()), "maai_bn_finalize_gathered")
+    return mean, invstd, scale, shift, count
 
 
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
@@ -675,16 +695,22 @@ def bn_act_bwd_reduce(dout, out, y, mean, relu):
 
 
 def bn_bwd_coeffs(sums, count, gamma, mean, invstd):
-    """``sums``: fp64 (local / reduced in fp64) or fp32 (the cross-rank exchange of SyncBatchNorm's backward)"""
+    """``sums``: fp64 (local / reduced in fp64) or fp32 (the cross-rank exchange of SyncBatchNorm's backward);
+    ``count``: a number, or the device double ``bn_finalize_gathered`` returned (SyncBatchNorm's merged count)"""
     c = mean.numel()
     dev = mean.device
     dgamma, dbeta, k1, k2, k3 = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(5))
+    cdev = None
+    if torch.is_tensor(count):
+        if count.dtype != torch.float64 or count.numel() != 1 or not count.is_cuda:
+            raise MaaiError("bn_bwd_coeffs: a device count is one fp64 element")
+        cdev, count = count, 0.0
     if sums.dtype == torch.float32:
         check(lib().maai_bn_bwd_coeffs_f32(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
-                                           _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs_f32")
+                                           _p(k2), _p(k3), c, _p(cdev), _stream()), "maai_bn_bwd_coeffs_f32")
     else:
         check(lib().maai_bn_bwd_coeffs(_p(sums), float(count), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(k1),
-                                       _p(k2), _p(k3), c, _stream()), "maai_bn_bwd_coeffs")
+                                       _p(k2), _p(k3), c, _p(cdev), _stream()), "maai_bn_bwd_coeffs")
     return dgamma, dbeta, k1, k2, k3
 
 
@@ -699,6 +725,48 @@ def bn_act_bwd_apply(dout, out, y, k1, k2, k3, relu, want_dy=True, want_dz=False
         check(lib().maai_bn_act_bwd_apply(_p(dout), _p(out), _p(y), _p(k1), _p(k2), _p(k3), _p(dy), _p(dz), m, c,
                                           1 if relu else 0, _dt(dout), _stream()), "maai_bn_act_bwd_apply")
     return dy, dz
+
+
+# ----------------------------------------------------------------------------
+# BatchNorm-backward folded through an expanding pointwise convolution (csrc/fold.hip; engine._FOLD)
+# ----------------------------------------------------------------------------
+def fold_s2(wq, g1, s1, mean):
+    """fp64 [Cout]: sum_k W[c,k] G1[c,k] - mean[c] s1[c]  (= sum g*(y - mean), y = x W^T never read)"""
+    _gpu(wq, g1, s1, mean)
+    cout, cin = g1.shape
+    if wq.dtype != torch.bfloat16 or wq.numel() != cout * cin or g1.dtype != torch.float32 or s1.dtype != torch.float64:
+        raise MaaiError("fold_s2: bf16 weights [Cout,Cin], fp32 G1, fp64 s1")
+    s2 = torch.empty(cout, dtype=torch.float64, device=g1.device)
+    check(lib().maai_fold_s2(_p(wq), _p(g1), _p(s1), _p(mean), _p(s2), cout, cin, _stream()), "maai_fold_s2")
+    return s2
+
+
+def fold_dw(wq, g1, gram, sx, k1, k2, k3):
+    """fp32 [Cout,Cin]: k1*G1 - k2 (x) sx - k3*(W Gram)"""
+    _gpu(wq, g1, gram, sx, k1, k2, k3)
+    cout, cin = g1.shape
+    if gram.dtype != torch.float32 or gram.numel() != cin * cin or sx.dtype != torch.float64 or sx.numel() < cin:
+        raise MaaiError("fold_dw: fp32 Gram [Cin,Cin], fp64 sx [Cin]")
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=g1.device)
+    check(lib().maai_fold_dw(_p(wq), _p(g1), _p(gram), _p(sx), _p(k1), _p(k2), _p(k3), _p(dw), cout, cin, _stream()), "maai_fold_dw")
+    return dw
+
+
+def fold_dgrad_weights(wq, k1, k2, k3, s1, sx, count):
+    """(wf [Cin,1,1,Cout] bf16 = k1*W in data-gradient form, tn [Cin,1,1,Cin] bf16 = -(W^T diag(k3) W), cn [Cin] fp32 = -(k2 W)
+    minus the pixel mean of what rounding wf and tn adds to dx: ``s1`` = sum g [Cout], ``sx`` = colsum x [Cin] (fp64) over
+    ``count`` pixels)"""
+    _gpu(wq, k1, k2, k3, s1, sx)
+    cout, cin = wq.shape[0], wq.numel() // wq.shape[0]
+    if s1.dtype != torch.float64 or sx.dtype != torch.float64 or s1.numel() < cout or sx.numel() < cin:
+        raise MaaiError("fold_dgrad_weights: fp64 s1 [Cout], sx [Cin]")
+    wf = torch.empty((cin, 1, 1, cout), dtype=torch.bfloat16, device=wq.device)
+    tn = torch.empty((cin, 1, 1, cin), dtype=torch.bfloat16, device=wq.device)
+    cn = torch.empty(cin, dtype=torch.float32, device=wq.device)
+    scratch = torch.empty(cin, dtype=torch.float32, device=wq.device)
+    check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), float(count), _p(wf), _p(tn), _p(cn), _p(scratch),
+                                  cout, cin, _stream()), "maai_fold_dgrad_w")
+    return wf, tn, cn
 
 
 # ----------------------------------------------------------------------------

@@ -161,6 +161,34 @@ if __name__ == "__main__":
     z = m.g(torch.nn.functional.adaptive_avg_pool2d(feat, (4, 4)))
     save("r50_pool.npz", z=z, feat_mean=feat.mean(dim=(2, 3)))
 
+    # ---- 4c. ResNet-50 AT THE TIMED RESOLUTION (BASELINE configs[1] topology): 3x224x224, reference stem, 4x4 adaptive pool
+    #          (resnet.py:181's commented variant), MLP(32768,1024,128); 2 uint8 images, train-mode BatchNorm ----
+    B = 2
+    x = inputs_uniform_u8(400, (B, 3, 224, 224)).float()
+    m = build_ref("resnet50", 1, 2048 * 16, B, (224, 224), 0.25); m.train()
+    feat = m.f(x)
+    z = m.g(torch.nn.functional.adaptive_avg_pool2d(feat, (4, 4)))
+    sd = m.state_dict()
+    save("r50_224.npz", z=z, feat_mean=feat.mean(dim=(2, 3)), feat_shape=np.array(feat.shape),
+         l1_bn3_rm=sd["f.layer1.0.bn3.running_mean"], l1_bn3_rv=sd["f.layer1.0.bn3.running_var"],
+         l4_bn3_rm=sd["f.layer4.2.bn3.running_mean"], l4_bn3_rv=sd["f.layer4.2.bn3.running_var"])
+
+    # ---- 4d. BASELINE configs[0] / SURVEY 8(d) cfg1 AS WRITTEN: torch.manual_seed(0), x1, x2 = randn(64,3,32,32),
+    #          resnet18(crop_measures=1), MLP(8192,1024,128), tau = 0.5, one two-view step (h1 detached) ----
+    torch.manual_seed(0)
+    x1 = torch.randn(64, 3, 32, 32)
+    x2 = torch.randn(64, 3, 32, 32)
+    m = build_ref("resnet18", 1, 512 * 16, 64, (32, 32), 0.25); m.train()
+    with torch.no_grad():
+        z1 = m.g(m.f(x1))
+    z2 = m.g(m.f(x2))
+    z2.retain_grad()
+    loss, logits, labels = Objective.contrastive_loss(hidden1=z1.data, hidden2=z2, temperature=0.5)
+    loss.backward()
+    save("r18_cfg1_literal.npz", z1=z1, z2=z2, loss=loss, dh2=z2.grad, logits=logits,
+         g_conv1=m.f.conv1.weight.grad, g_fc2_b=m.g.layers[2].bias.grad,
+         gnorms=np.array([p.grad.norm().item() for p in m.parameters()]))
+
     # ---- 5. host utilities ----
     class A:  # minimal stand-in for the optimizer the schedule reads (Model_Util.py:11-15)
         pass

@@ -50,6 +50,8 @@ CASES = [
     (4, 64, 48),
     (16, 56, 56),     # 3136 patches on 1536 waves: two or three patches per wave (prefetch, halo reuse, sums across patches)
     (2, 224, 224),    # the benchmark's plane
+    (2, 20, 20),      # W % 16 in 1..6: the last patch column ends inside the halo's FIRST column group (the
+    (1, 33, 35),      # missing "< W" test loaded the next row's pixels — and ran past the tensor on the last row)
 ]
 
 
@@ -96,7 +98,7 @@ def test_forward_matches_halo_kernel(K, case, mode):
 
 
 @pytest.mark.parametrize("mask", ["from_y", "bits", "tensor", "none"])
-@pytest.mark.parametrize("case", [(2, 32, 32), (3, 30, 30), (16, 56, 56)], ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("case", [(2, 32, 32), (3, 30, 30), (16, 56, 56), (2, 20, 20), (1, 33, 35)], ids=lambda c: "x".join(map(str, c)))
 def test_data_gradient_epilogue_matches_halo_kernel(K, case, mask):
     """dx = conv(dy, W^T) * [unit below's output > 0] with the BatchNorm-backward partial sums of the stored gradient."""
     n, h, w_ = case

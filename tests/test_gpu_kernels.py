@@ -532,9 +532,10 @@ def test_syncbn_packed_statistics_merge(K, world, counts):
     assert not gathered.is_contiguous() or world == 1
     gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
     rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-    mean, invstd, scale, shift = K.bn_finalize_gathered(gathered, gamma, beta, rm, rv, 0.1, 1e-5)
+    mean, invstd, scale, shift, ncount = K.bn_finalize_gathered(gathered, gamma, beta, rm, rv, 0.1, 1e-5)
     allx = torch.cat(xs)
     n = allx.shape[0]
+    assert ncount.dtype == torch.float64 and ncount.item() == float(n)   # the merged count: sum of the ranks' (unequal) counts
     m_ref, v_ref = allx.mean(0), allx.var(0, unbiased=False)
     np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), rtol=2e-7, atol=1e-6)
     np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(v_ref + 1e-5)).numpy(), rtol=2e-5)
@@ -554,6 +555,10 @@ def test_syncbn_packed_statistics_merge(K, world, counts):
     b = K.bn_bwd_coeffs(s64.float(), n, gamma, mean, invstd)
     for u, v in zip(a, b):
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # ... and with the count taken from the device scalar of the merge (what the engine's SyncBatchNorm backward passes:
+    # the ranks' batches may differ) exactly as with the host number
+    for u, v in zip(a, K.bn_bwd_coeffs(s64, ncount, gamma, mean, invstd)):
+        assert torch.equal(u, v)
 
 
 def test_augment_bit_exact(K):

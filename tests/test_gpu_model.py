@@ -158,6 +158,63 @@ def test_resnet50_pooled_head_fp32(mods, golden_dir):
     np.testing.assert_allclose(z.cpu().numpy(), G["z"], rtol=2e-3, atol=2e-4)
 
 
+def test_resnet50_at_224_fp32_against_reference_golden(mods, golden_dir):
+    """The benchmark's own topology AT ITS OWN RESOLUTION against the reference: resnet50(crop_measures=1)
+    on 2 uint8 images at 3x224x224 (stride-1 7x7 stem, [2,2048,28,28] map, resnet.py:226-240) -> 4x4 adaptive pool ->
+    MLP(32768,1024,128), train-mode BatchNorm; fp32 mode at the tolerances of the other fp32 goldens."""
+    G = np.load(os.path.join(golden_dir, "r50_224.npz"))
+    mods["engine"].set_precision("fp32")
+    x = _u8(400, (2, 3, 224, 224)).float().cuda()
+    m = _build(mods, "resnet50", 1, 2048 * 16, 2, (224, 224), 0.25)
+    m.train()
+    with torch.no_grad():
+        feat = m.f(x)
+    assert list(feat.shape) == [2, 2048, 28, 28]
+    np.testing.assert_allclose(feat.mean(dim=(2, 3)).cpu().numpy(), G["feat_mean"], rtol=2e-3, atol=2e-4)
+    sd = m.state_dict()
+    for key, name in (("l1_bn3", "f.layer1.0.bn3"), ("l4_bn3", "f.layer4.2.bn3")):
+        np.testing.assert_allclose(sd[name + ".running_mean"].cpu().numpy(), G[key + "_rm"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(sd[name + ".running_var"].cpu().numpy(), G[key + "_rv"], rtol=1e-3)
+    m2 = _build(mods, "resnet50", 1, 2048 * 16, 2, (224, 224), 0.25)
+    m2.train()
+    m2.head_pool = 4
+    with torch.no_grad():
+        z = m2.forward_tensor(x)
+    np.testing.assert_allclose(z.cpu().numpy(), G["z"], rtol=2e-3, atol=2e-4)
+
+
+def test_resnet18_cfg1_literal_fp32_against_reference_golden(mods, golden_dir):
+    """BASELINE configs[0] / SURVEY 8(d) cfg1 as written: torch.manual_seed(0), x1, x2 =
+    randn(64,3,32,32), resnet18(crop_measures=1), MLP(8192,1024,128), tau = 0.5 — embeddings, loss, logits, dL/dh2 and
+    parameter gradients of one two-view step (Contrastive_Learning.py:638-700)."""
+    G = np.load(os.path.join(golden_dir, "r18_cfg1_literal.npz"))
+    mods["engine"].set_precision("fp32")
+    torch.manual_seed(0)
+    x1 = torch.randn(64, 3, 32, 32)
+    x2 = torch.randn(64, 3, 32, 32)
+    m = _build(mods, "resnet18", 1, 512 * 16, 64, (32, 32), 0.25)
+    m.train()
+    with torch.no_grad():
+        h1 = m.forward_tensor(x1.cuda())
+    h2 = m.forward_tensor(x2.cuda())
+    h2.retain_grad()
+    loss, logits, labels = mods["Objective"].contrastive_loss(hidden1=h1.data, hidden2=h2, temperature=0.5)
+    loss.backward()
+    np.testing.assert_allclose(h1.cpu().numpy(), G["z1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(h2.detach().cpu().numpy(), G["z2"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(loss.item(), G["loss"], rtol=1e-5)
+    np.testing.assert_allclose(logits.cpu().numpy(), G["logits"], rtol=1e-3, atol=1e-4)
+    assert labels.shape == (64, 128) and labels.dtype == torch.int64
+    ref = G["dh2"]
+    assert np.abs(h2.grad.cpu().numpy() - ref).max() < 2e-3 * np.abs(ref).max()
+    for key, p in (("g_conv1", m.f.conv1.weight), ("g_fc2_b", m.g.layers[2].bias)):
+        got, r = p.grad.cpu().numpy().astype(np.float64).ravel(), G[key].astype(np.float64).ravel()
+        cos = float(got @ r / (np.linalg.norm(got) * np.linalg.norm(r)))
+        assert cos > 0.9995 and abs(np.linalg.norm(got) / np.linalg.norm(r) - 1) < 1e-2, (key, cos)
+    gn = np.array([p.grad.norm().item() for p in m.parameters()])
+    np.testing.assert_allclose(gn, G["gnorms"], rtol=2e-2)
+
+
 def test_bf16_production_path_end_to_end_resnet18(mods):
     """bf16 storage / fp32 accumulate vs the oracle rounding at the same points, end to end.  Residual
     blocks amplify the 2^-9 rounding noise (tests/test_oracle_golden.py::test_bf16_storage_mode_close_to_fp32;
@@ -183,24 +240,26 @@ def test_bf16_production_path_end_to_end_resnet18(mods):
     np.testing.assert_allclose(m.state_dict()[key].cpu().numpy(), ns[key].numpy(), rtol=2e-2)
 
 
-# ResNet-50 end to end in bf16 is ill-conditioned even at residual_gamma = 0.25 with 8 images (the CPU oracle's OWN bf16-storage
-# run differs from its fp32 run by 0.46 of max|z|, min cosine 0.55): the assertion is relative to that yardstick.
-R50_BF16_E2E = {"rel_over_oracle_gap": 2.5}
+# ResNet-50 end to end in bf16.  A randomly initialised ResNet-50 with unit-scale residual branches doubles
+# a perturbation per block: at 8 images the oracle's OWN bf16-storage run is decorrelated from its fp32 run (cosine 0.55), and
+# an assertion there can only be relative to that gap.  The regime below — 64 images at the native 12x30x30, residual_gamma
+# 0.02 (the knob zero_init_residual sets to 0, resnet.py:194-199) — is the one in which the oracle's bf16 and fp32 runs agree to
+# cosine > 0.993 per row and 0.5 % of the loss (tests/test_oracle_golden.py::test_resnet50_bf16_regime_is_well_conditioned), so
+# the bounds are absolute.
+R50_BF16_E2E = {"batch": 64, "residual_gamma": 0.02, "min_row_cosine": 0.99, "loss_rel": 1e-2}
 
 
-def test_bf16_production_path_end_to_end_resnet50_reported(mods, record_property):
-    """the timed (bf16) mode END TO END on ResNet-50 — the reference's native 12x30x30 input through
-    SimCLR_Module.forward (SimCLR.py:23-31), residual_gamma = 0.25 (where the network is well conditioned: fp32 == fp64 to
-    1e-4, tests/test_oracle_golden.py) — against the oracle's storage="bf16" run on the same inputs.  The number is
-    REPORTED (printed, recorded as a test property, quoted in DESIGN section 2) and asserted with margin; per-block parity
-    (2^-6) is what test_every_block_teacher_forced pins."""
-    B = 8
+def test_bf16_production_path_end_to_end_resnet50(mods, record_property):
+    """The timed (bf16) mode END TO END on ResNet-50 through SimCLR_Module.forward (SimCLR.py:23-31): 64 x 4 uint8 views,
+    train-mode BatchNorm, against the oracle's storage="bf16" run AND its fp32 run: every row of z within cosine 0.99, the
+    NT-Xent loss on the embeddings within 1 %."""
+    B, rg = R50_BF16_E2E["batch"], R50_BF16_E2E["residual_gamma"]
     views = [_u8(200 + k, (B, 30, 30, 3)) for k in range(4)]
-    sd = O.pattern_state_dict("resnet50", 4, 2048 * 16, residual_gamma=0.25)
+    sd = O.pattern_state_dict("resnet50", 4, 2048 * 16, residual_gamma=rg)
     x = O.pack_views(views, B, (30, 30))
     z_ref = O.simclr_forward(sd, x, "resnet50", True, "bf16")
     z_f32 = O.simclr_forward(sd, x, "resnet50", True, "fp32")
-    m = _build(mods, "resnet50", 4, 2048 * 16, B, (30, 30), 0.25)
+    m = _build(mods, "resnet50", 4, 2048 * 16, B, (30, 30), rg)
     m.train()
     with torch.no_grad():
         z = m([v.cuda() for v in views]).cpu()
@@ -208,19 +267,21 @@ def test_bf16_production_path_end_to_end_resnet50_reported(mods, record_property
     cos = torch.nn.functional.cosine_similarity(z, z_ref, dim=1).min().item()
     rel32 = ((z - z_f32).abs().max() / z_f32.abs().max()).item()
     cos32 = torch.nn.functional.cosine_similarity(z, z_f32, dim=1).min().item()
-    orel = ((z_ref - z_f32).abs().max() / z_f32.abs().max()).item()   # the oracle's own bf16-vs-fp32 distance: the yardstick
+    ocos = torch.nn.functional.cosine_similarity(z_ref, z_f32, dim=1).min().item()
     l_ref = O.nt_xent(z_ref, z_ref.flip(0), 0.5)[0].item()
+    l_f32 = O.nt_xent(z_f32, z_f32.flip(0), 0.5)[0].item()
     l_got = O.nt_xent(z, z.flip(0), 0.5)[0].item()
-    msg = ("R50 12x30x30 bf16 end to end (gamma 0.25): max|z - z_oracle_bf16|/max|z| = %.3e, min cos = %.5f; vs oracle fp32: %.3e, cos %.5f; "
-           "oracle bf16 vs oracle fp32: %.3e; NT-Xent on z: %.6f vs %.6f" % (rel, cos, rel32, cos32, orel, l_got, l_ref))
+    msg = ("R50 12x30x30 x %d bf16 end to end (gamma %g): vs oracle bf16: max|dz|/max|z| = %.3e, min row cos = %.5f; vs oracle fp32: "
+           "%.3e, cos %.5f; oracle bf16 vs fp32 min cos %.5f; NT-Xent on z: %.6f (HIP) / %.6f (oracle bf16) / %.6f (oracle fp32)"
+           % (B, rg, rel, cos, rel32, cos32, ocos, l_got, l_ref, l_f32))
     print(msg)
     record_property("r50_bf16_e2e", msg)
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "r50_bf16_e2e.txt"), "w") as fh:
             fh.write(msg + "\n")
-    assert rel < R50_BF16_E2E["rel_over_oracle_gap"] * orel + 0.05, msg
-    assert abs(l_got - l_ref) / l_ref < 0.2, msg
+    assert cos >= R50_BF16_E2E["min_row_cosine"] and cos32 >= R50_BF16_E2E["min_row_cosine"], msg
+    assert abs(l_got - l_ref) / l_ref < R50_BF16_E2E["loss_rel"] and abs(l_got - l_f32) / l_f32 < R50_BF16_E2E["loss_rel"], msg
 
 
 def _nchw(t):

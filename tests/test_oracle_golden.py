@@ -123,6 +123,63 @@ def test_resnet50_pool_head(golden_dir):
     np.testing.assert_allclose(z.numpy(), G["z"], rtol=2e-3, atol=2e-4)
 
 
+def test_resnet50_at_224_timed_topology(golden_dir):
+    """The reference's resnet50(crop_measures=1) at the benchmark's own resolution (BASELINE configs[1]: 3x224x224, stride-1
+    stem, [B,2048,28,28] map, 4x4 adaptive pool, MLP(32768,1024,128)) on 2 uint8 images, train-mode BatchNorm."""
+    G = _load(golden_dir, "r50_224.npz")
+    x = _u8(400, (2, 3, 224, 224)).float()
+    sd = O.pattern_state_dict("resnet50", 1, 2048 * 16, residual_gamma=0.25)
+    ns = {}
+    feat = O.backbone_forward(sd, x, "resnet50", True, "fp32", ns)
+    assert list(feat.shape) == list(G["feat_shape"]) == [2, 2048, 28, 28]
+    np.testing.assert_allclose(feat.mean(dim=(2, 3)).numpy(), G["feat_mean"], rtol=2e-3, atol=2e-4)
+    z = O.head_forward(sd, feat, pool=4)
+    np.testing.assert_allclose(z.numpy(), G["z"], rtol=2e-3, atol=2e-4)
+    for key, name in (("l1_bn3", "f.layer1.0.bn3"), ("l4_bn3", "f.layer4.2.bn3")):
+        np.testing.assert_allclose(ns[name + ".running_mean"].numpy(), G[key + "_rm"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(ns[name + ".running_var"].numpy(), G[key + "_rv"], rtol=1e-3)
+
+
+def test_resnet18_cfg1_literal(golden_dir):
+    """BASELINE configs[0] / SURVEY 8(d) cfg1 exactly as written: torch.manual_seed(0); x1, x2 = randn(64,3,32,32);
+    resnet18(crop_measures=1) + MLP(8192,1024,128), tau = 0.5, one two-view step with h1 detached."""
+    G = _load(golden_dir, "r18_cfg1_literal.npz")
+    torch.manual_seed(0)
+    x1 = torch.randn(64, 3, 32, 32)
+    x2 = torch.randn(64, 3, 32, 32)
+    sd = O.pattern_state_dict("resnet18", 1, 512 * 16, residual_gamma=0.25)
+    r = O.train_step(sd, {}, x1, x2, "resnet18", 0.5, 1e-3)
+    np.testing.assert_allclose(r["z1"].numpy(), G["z1"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["z2"].numpy(), G["z2"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(r["loss"].item(), G["loss"], rtol=1e-5)
+    np.testing.assert_allclose(r["logits"].numpy(), G["logits"], rtol=1e-3, atol=1e-4)
+    _, dh2 = O.nt_xent_grad_h2(r["z1"], r["z2"], 0.5)
+    np.testing.assert_allclose(dh2.numpy(), G["dh2"], rtol=1e-3, atol=1e-7)
+    g = r["grads"]
+    for key, name in (("g_conv1", "f.conv1.weight"), ("g_fc2_b", "g.layers.2.bias")):
+        ref = G[key]
+        assert np.abs(g[name].numpy() - ref).max() / np.abs(ref).max() < 1e-2, key
+    gn = np.array([g[k].norm().item() for k in O.trainable_keys(sd)])
+    np.testing.assert_allclose(gn, G["gnorms"], rtol=1e-2)
+
+
+def test_resnet50_bf16_regime_is_well_conditioned():
+    """The regime of the GPU test that holds the timed (bf16) path END TO END (tests/test_gpu_model.py::
+    test_bf16_production_path_end_to_end_resnet50): 64 images at the native 12x30x30 with residual_gamma = 0.02 — here the
+    oracle's own bf16-storage run agrees with its fp32 run to cosine >= 0.99 per row and 1 % of the NT-Xent loss, so a
+    disagreement of the HIP path beyond that is the kernels', not the network's conditioning."""
+    B = 64
+    views = [_u8(200 + k, (B, 30, 30, 3)) for k in range(4)]
+    sd = O.pattern_state_dict("resnet50", 4, 2048 * 16, residual_gamma=0.02)
+    x = O.pack_views(views, B, (30, 30))
+    zb = O.simclr_forward(sd, x, "resnet50", True, "bf16")
+    zf = O.simclr_forward(sd, x, "resnet50", True, "fp32")
+    cos = torch.nn.functional.cosine_similarity(zb, zf, dim=1)
+    assert cos.min() > 0.993, cos.min().item()
+    lb, lf = O.nt_xent(zb, zb.flip(0), 0.5)[0].item(), O.nt_xent(zf, zf.flip(0), 0.5)[0].item()
+    assert abs(lb - lf) / lf < 5e-3, (lb, lf)
+
+
 def test_bf16_storage_mode_close_to_fp32():
     """Document how far the bf16-storage emulation sits from fp32: the distance is
     a property of the network's conditioning (every residual block of a randomly
