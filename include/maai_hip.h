@@ -325,16 +325,34 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
  *   maai_fold_dw:      dw[c,k] = k1[c] G1[c,k] - k2[c] sx[k] - k3[c] (W Gram)[c,k]  (= (k1*g - k2 - k3*y)^T x)
  *   maai_fold_dgrad_w: wf[k][c] = bf16(k1[c] W[c,k]), tn[k][j] = bf16(-(W^T diag(k3) W)[j,k]), cn[k] = -(k2 W)[k] - comp[k], so that
  *                      dx = g wf^T + x tn^T + cn                                    (= (k1*g - k2 - k3*y) W)
- *                      comp[k] = (s1 . (wf[k] - exact) + sx . (tn[k] - exact)) / count: the pixel mean of what the bf16 rounding
- *                      of the folded weights adds to dx[:, k] (s1 = sum g, sx = colsum x over `count` pixels) — taken out of the
- *                      constant so that this rounding error is zero-mean over the pixels; scratch: Cin floats.
+ *                      comp[k] = the mean, over the pixels output channel k's ReLU mask keeps, of what the bf16 rounding of the
+ *                      folded weights adds to dx[:, k]: (s1 . (wf[k] - exact) + sum_{j != k} sx[j] (tn[k][j] - exact)) / count
+ *                      + sx[k] (tn[k][k] - exact) / npos[k]  (s1 = sum g, sx = colsum x over `count` pixels, npos[k] = pixels with
+ *                      x_k > 0, nullable -> count) — taken out of the constant so that this rounding error is zero-mean where it
+ *                      counts; scratch: Cin floats.
  * w: the bf16 kernel-layout weights [Cout][Cin]; g1, gram, dw fp32; s1, s2, sx fp64; k1..k3 as maai_bn_bwd_coeffs gives them.
  * ------------------------------------------------------------------------ */
 int maai_fold_s2(const void* w, const float* g1, const double* s1, const float* mean, double* s2, int Cout, int Cin, void* stream);
 int maai_fold_dw(const void* w, const float* g1, const float* gram, const double* sx, const float* k1, const float* k2,
                  const float* k3, float* dw, int Cout, int Cin, void* stream);
 int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const float* k3, const double* s1, const double* sx,
-                      double count, void* wf, void* tn, float* cn, float* scratch, int Cout, int Cin, void* stream);
+                      const double* npos, double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* scratch, int Cout, int Cin,
+                      void* stream);
+/* wf_pitch / tn_pitch: row pitches (elements) of wf [Cin rows] and tn [Cin rows]: Cout and Cin for two separate matrices, or
+ * both Cout + Cin with tn = wf + Cout for the concatenated form Wcat [Cin][Cout + Cin] that maai_conv_dfold multiplies by.
+ *
+ * maai_gram (csrc/gram.hip): gram [C][C] fp32 += x^T x, sx [C] fp64 += colsum(x), npos [C] fp64 (nullable) += rows with x > 0, over
+ * the M rows of x [M][C] bf16 (C = 64, 128, 256, 512); xs / xt (nullable, [C]) + x_relu: x is act(raw*xs + xt) formed on load
+ * (maai_bn_act_fwd arithmetic).
+ * maai_conv_dfold (csrc/conv_dfold.hip): the folded unit's data gradient for the 64 -> 256 units of layer 1 in one launch —
+ *   dx[M][64] = ([g | a2] Wcat^T + cn) * [a2 > 0],  a2 = relu(r(y2*s2 + t2)) formed on load from the raw y2 [M][64], g [M][256],
+ *   (+)= when accumulate; slab [maai_conv_dfold_rows(M)][2][64]: partial sums of dx and dx*(y2 - mean2) (the unit below's
+ *   BatchNorm backward). */
+int maai_gram(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* gram, double* sx, double* npos,
+              void* stream);
+long long maai_conv_dfold_rows(long long M);
+int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* mean2, const float* s2, const float* t2,
+                    void* dx, float* slab, long long M, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------
  * Comm helper: one-shot direct all-gather over the xGMI mesh (symmetric buffers, peer-to-peer stores) — the

@@ -272,7 +272,8 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   MAAI_CHECK_ARG(emode >= 0 && emode <= MAAI_EPI_DGRAD_REDUCE, "conv2d_igemm: bad epilogue mode");
   MAAI_CHECK_ARG(y || emode == MAAI_EPI_STATS_ONLY || emode == MAAI_EPI_BWD_REDUCE, "conv2d_igemm: null output");
   MAAI_CHECK_ARG((emode != MAAI_EPI_STATS_ONLY && emode != MAAI_EPI_BWD_REDUCE && emode != MAAI_EPI_DGRAD_REDUCE) || stats_partial, "conv2d_igemm: this epilogue needs the partial-sum slab");
-  MAAI_CHECK_ARG(emode < MAAI_EPI_BWD_REDUCE || epi->t, "conv2d_igemm: BN-backward epilogues need dz (DGRAD_REDUCE: the raw conv output)");
+  MAAI_CHECK_ARG(emode < MAAI_EPI_BWD_REDUCE || epi->t || (emode == MAAI_EPI_DGRAD_REDUCE && relu_mask),
+                 "conv2d_igemm: BN-backward epilogues need dz (DGRAD_REDUCE: the raw conv output, or — first sum only — a mask)");
   MAAI_CHECK_ARG(emode != MAAI_EPI_BWD_APPLY || (epi->p0 && epi->p1 && epi->p2), "conv2d_igemm: BN-backward apply needs k1, k2, k3");
   MAAI_CHECK_ARG(emode < 2 || emode == MAAI_EPI_DGRAD_REDUCE || (!d->accumulate && !relu_mask && d->out_stride == 1), "conv2d_igemm: fused BN epilogues are dense, non-accumulating");
   MAAI_CHECK_ARG(dtype == MAAI_BF16 || dtype == MAAI_F32, "conv2d_igemm: dtype must be MAAI_BF16 or MAAI_F32");
@@ -318,6 +319,10 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.pre_cin = epi ? epi->pre_cin : 0;
   a.pre_y_out = epi ? epi->pre_y_out : nullptr;
   const bool pws = pws_selected(d, epi, dtype);
+  if (a.x_bits && !a.xb) {
+    MAAI_CHECK_ARG(emode == MAAI_EPI_BN_ACT && pws && !a.xs && a.erelu && dtype == MAAI_BF16,
+                   "conv2d_igemm: x_bits without a two-tensor join is the mask output of the streaming kernel's BatchNorm + ReLU epilogue");
+  }
   if (a.xs || a.xb) {
     MAAI_CHECK_ARG(a.xs && a.xt && (emode == MAAI_EPI_STORE || ((emode == MAAI_EPI_STATS_ONLY || (emode == MAAI_EPI_BN_ACT && !a.xb)) && pws)) && !d->accumulate && !relu_mask &&
                        d->out_stride == 1 && !a.a2,

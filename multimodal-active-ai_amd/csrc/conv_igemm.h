@@ -682,7 +682,11 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
         mb8[b] = 0;
         if (ok[b]) {
           if (a.accumulate) vo[b].load(y + ooff);
-          if constexpr (EMODE == 6) vy[b].load(reinterpret_cast<const T*>(a.et) + ooff);
+          if constexpr (EMODE == 6) {
+            // (et null: the unit below needs the sum of the stored gradient only — its BatchNorm backward is folded through
+            //  its convolution and never reads its raw output; the second sum is then meaningless and ignored)
+            if (a.et) vy[b].load(reinterpret_cast<const T*>(a.et) + ooff); else vy[b].zero();
+          }
           if (a.mask) {
             if (EMODE == 6 && NV == 8 && a.mask_bits)
               mb8[b] = reinterpret_cast<const unsigned char*>(a.mask)[ooff >> 3];

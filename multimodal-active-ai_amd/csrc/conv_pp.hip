@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
         mb8[b] = 0;
         if (ok[b]) {
           if (a.accumulate) vo[b].load(y + off[b]);
-          vy[b].load(et + off[b]);
+          if (et) vy[b].load(et + off[b]); else vy[b].zero();   // (null: sum of the stored gradient only, see conv_igemm.h)
           if (a.mask) {
             if (a.mask_bits) mb8[b] = reinterpret_cast<const unsigned char*>(a.mask)[off[b] >> 3];
             else vm[b].load(reinterpret_cast<const T*>(a.mask) + off[b]);

@@ -36,8 +36,10 @@ __device__ __forceinline__ void wait_vm() {
 // 2: MAAI_EPI_BN_ACT — frozen statistics: out = act(r(y)*scale + shift (+ residual)) applied to the bf16-rounded tile on its
 // way out (the arithmetic of maai_bn_act_fwd on the stored tensor: bit-identical to launch + pass), no raw output in HBM.
 // RES (EMODE 2): a residual tensor is added; its tile is requested a whole column tile ahead (before the K loop), and the
-// loads enter the vmcnt bookkeeping next to the stores they follow.
-template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false>
+// loads enter the vmcnt bookkeeping next to the stores they follow.  BITS (EMODE 2): the 1-bit ReLU mask of the stored output
+// goes to a.x_bits (one byte per 16-byte chunk, the layout of maai_bn_act_fwd_mask) — the training forward of a unit whose
+// raw output is never stored (engine._FOLD) keeps it for the backward pass.
+template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false, bool BITS = false>
 __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
   typedef bf16_t T;
   constexpr int TM = 2, BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
   constexpr int RPI = 64 / CPR;            // rows one wave-wide 16-byte access covers
   constexpr int NIT = 16 / RPI;            // such accesses per 16-row group
-  constexpr int NST = (EMODE == 1 ? 0 : TM * NIT) * (RES ? 2 : 1);   // global stores (+ residual loads) per wave per column tile
+  constexpr int NST = (EMODE == 1 ? 0 : TM * NIT) * ((RES ? 2 : 1) + (BITS ? 1 : 0));   // global stores (+ residual loads, + mask bytes) per wave per column tile
   constexpr int NSLOT = DIST + 2;
   constexpr int RING = NSLOT * STAGE;
   typedef Mma<T>::frag frag_t;
@@ -318,7 +320,14 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
             for (int e = 0; e < 8; ++e) fv[e] = fmaxf(fv[e], 0.f);
           }
           v.set(fv);
-          if (full || m0 + it * RPI < a.M) v.store(dst + (long long)it * RPI * a.Cout);
+          if (full || m0 + it * RPI < a.M) {
+            v.store(dst + (long long)it * RPI * a.Cout);
+            if constexpr (BITS) {
+              const unsigned b = nonzero_bits_bf16x2(v.raw.x) | (nonzero_bits_bf16x2(v.raw.y) << 2) | (nonzero_bits_bf16x2(v.raw.z) << 4) |
+                                 (nonzero_bits_bf16x2(v.raw.w) << 6);   // (post-ReLU values: non-zero == positive)
+              a.x_bits[((m0 + it * RPI) * a.Cout + ct * BN + (lane % CPR) * 8) >> 3] = (unsigned char)b;
+            }
+          }
         }
       } else {
 #pragma unroll
@@ -338,15 +347,15 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   finish_stats(nCT - 1);
 }
 
-template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false>
+template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false, bool BITS = false>
 static int launch_pws(ConvArgs a, hipStream_t st) {
   constexpr int lds = (DIST + 2) * BN * 64 + 4 * 16 * (BN + 8) * 2 + 32 * BN * 4;
   static_assert(4 * KC * 4 <= 4 * 16 * (BN + 8) * 2, "the coefficient table borrows the C area");
   a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
-  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), lds, attr_lds);
-  MAAI_NOTE_KERNEL(conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>);
-  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+  maai_ensure_lds(reinterpret_cast<const void*>(&conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES, BITS>), lds, attr_lds);
+  MAAI_NOTE_KERNEL(conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES, BITS>);
+  hipLaunchKernelGGL((conv_pws_kernel<KC, BN, DIST, XF, EMODE, RES, BITS>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }
@@ -372,6 +381,13 @@ static int pws_k(const ConvArgs& a, hipStream_t st) {
     }
     ConvArgs b = a;
     b.stats = nullptr;   // (the statistics scratch holds the coefficient table)
+    if (a.x_bits) {      // the training forward of a folded unit: a ReLU output with its 1-bit mask (tensor input)
+      if (!a.erelu || a.xs) {
+        maai_set_error("conv2d_igemm: the mask output of the BatchNorm epilogue belongs to a ReLU unit with a tensor input");
+        return MAAI_ERR_UNSUPPORTED;
+      }
+      return a.et ? launch_pws<KC, BN, DIST, 0, 2, true, true>(b, st) : launch_pws<KC, BN, DIST, 0, 2, false, true>(b, st);
+    }
     if (a.et) return a.xs ? launch_pws<KC, BN, DIST, 1, 2, true>(b, st) : launch_pws<KC, BN, DIST, 0, 2, true>(b, st);
     return a.xs ? launch_pws<KC, BN, DIST, 1, 2, false>(b, st) : launch_pws<KC, BN, DIST, 0, 2, false>(b, st);
   }

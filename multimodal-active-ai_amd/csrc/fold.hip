@@ -41,9 +41,13 @@ __global__ __launch_bounds__(256) void fold_dw_kernel(const bf16_t* __restrict__
 }
 
 // Tn[k][j] = bf16(-sum_c W[c][j] k3[c] W[c][k]): block = one k (row of Tn), threads stride over j; k3 * W[:, k] staged in LDS.
-// ct[k] = sum_j sx[j] * (Tn[k][j] - exact): what rounding Tn to bf16 adds to the COLUMN SUM of dx[:, k] (see fold_wf_kernel).
+// ct[k] = the mean, over the pixels the mask of output channel k KEEPS, of what rounding Tn to bf16 adds to dx[:, k] (see
+// fold_wf_kernel): sum_j dTn[k][j] * E[x_j | x_k > 0].  For j != k that conditional mean is taken as the plain mean sx[j] / N;
+// for j == k — the dominant entry: T's diagonal is a sum of squares — it is EXACT: x_k is zero wherever the mask drops the
+// pixel (the mask is x_k > 0, x post-ReLU), so sum_p mask*x_k = sx[k] over npos[k] kept pixels.
 __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ w, const float* __restrict__ k3, const double* __restrict__ sx,
-                                                     bf16_t* __restrict__ tn, float* __restrict__ ct, int Cout, int Cin) {
+                                                     const double* __restrict__ npos, double inv_n, bf16_t* __restrict__ tn, int tn_pitch,
+                                                     float* __restrict__ ct, int Cout, int Cin) {
   extern __shared__ float wk[];   // k3[c] * W[c][k]
   __shared__ float red[256];
   const int k = blockIdx.x;
@@ -54,8 +58,9 @@ __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ 
     float acc = 0.f;
     for (int c = 0; c < Cout; ++c) acc = fmaf(bf16_to_f32(w[(long long)c * Cin + j]), wk[c], acc);
     const bf16_t r = f32_to_bf16(-acc);
-    tn[(long long)k * Cin + j] = r;
-    bias = fmaf((float)sx[j], bf16_to_f32(r) + acc, bias);
+    tn[(long long)k * tn_pitch + j] = r;
+    const double kept = (j == k && npos && npos[k] >= 1.0) ? 1.0 / npos[k] : inv_n;
+    bias = fmaf((float)(sx[j] * kept), bf16_to_f32(r) + acc, bias);
   }
   red[threadIdx.x] = bias;
   __syncthreads();
@@ -69,11 +74,12 @@ __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ 
 // Wf[k][c] = bf16(k1[c] W[c][k]); cn[k] = -sum_c k2[c] W[c][k] - (rounding compensation): block = one k, threads over c.
 // Rounding the folded weights to bf16 perturbs dx[p][k] by g[p] . dWf[k] + x[p] . dTn[k] — tiny per element, but COHERENT over
 // the pixels (the same weight error meets the non-zero means of g and of the post-ReLU x), which is exactly what the
-// BatchNorm-backward sums of the unit below add up.  Its pixel mean, (s1 . dWf[k] + sx . dTn[k]) / N, is known here and is
-// taken out of the constant: the rounding error of the folded weights is then zero-mean over the pixels.
+// BatchNorm-backward sums of the unit below add up.  Its mean over the pixels the mask keeps — s1 . dWf[k] / N (g taken as
+// independent of the mask) + fold_t_kernel's ct[k] — is known here and is taken out of the constant: the rounding error of the
+// folded weights is then zero-mean over the pixels that survive the mask (the constant only ever reaches those).
 __global__ __launch_bounds__(256) void fold_wf_kernel(const bf16_t* __restrict__ w, const float* __restrict__ k1, const float* __restrict__ k2,
                                                       const double* __restrict__ s1, const float* __restrict__ ct, double inv_n,
-                                                      bf16_t* __restrict__ wf, float* __restrict__ cn, int Cout, int Cin) {
+                                                      bf16_t* __restrict__ wf, int wf_pitch, float* __restrict__ cn, int Cout, int Cin) {
   __shared__ float red[256], red2[256];
   const int k = blockIdx.x;
   float part = 0.f, bias = 0.f;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(256) void fold_wf_kernel(const bf16_t* __restrict__
     const float v = bf16_to_f32(w[(long long)c * Cin + k]);
     const float exact = k1[c] * v;
     const bf16_t r = f32_to_bf16(exact);
-    wf[(long long)k * Cout + c] = r;
+    wf[(long long)k * wf_pitch + c] = r;
     part = fmaf(k2[c], v, part);
     bias = fmaf((float)s1[c], bf16_to_f32(r) - exact, bias);
   }
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(256) void fold_wf_kernel(const bf16_t* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) cn[k] = -red[0] - (float)((double)(red2[0] + ct[k]) * inv_n);
+  if (threadIdx.x == 0) cn[k] = -red[0] - (float)((double)red2[0] * inv_n) - ct[k];
 }
 
 extern "C" int maai_fold_s2(const void* w, const float* g1, const double* s1, const float* mean, double* s2, int Cout, int Cin, void* stream) {
@@ -116,12 +122,14 @@ extern "C" int maai_fold_dw(const void* w, const float* g1, const float* gram, c
 }
 
 extern "C" int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const float* k3, const double* s1, const double* sx,
-                                 double count, void* wf, void* tn, float* cn, float* scratch, int Cout, int Cin, void* stream) {
-  MAAI_CHECK_ARG(w && k1 && k2 && k3 && s1 && sx && wf && tn && cn && scratch && count > 0 && Cout > 0 && Cin > 0 && Cout <= 8192,
+                                 const double* npos, double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* scratch, int Cout, int Cin,
+                                 void* stream) {
+  MAAI_CHECK_ARG(w && k1 && k2 && k3 && s1 && sx && wf && tn && cn && scratch && count > 0 && Cout > 0 && Cin > 0 && Cout <= 8192 &&
+                     wf_pitch >= Cout && tn_pitch >= Cin,
                  "fold_dgrad_w: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(fold_t_kernel, dim3(Cin), dim3(256), Cout * sizeof(float), st, (const bf16_t*)w, k3, sx, (bf16_t*)tn, scratch, Cout, Cin);
-  hipLaunchKernelGGL(fold_wf_kernel, dim3(Cin), dim3(256), 0, st, (const bf16_t*)w, k1, k2, s1, scratch, 1.0 / count, (bf16_t*)wf, cn, Cout, Cin);
+  hipLaunchKernelGGL(fold_t_kernel, dim3(Cin), dim3(256), Cout * sizeof(float), st, (const bf16_t*)w, k3, sx, npos, 1.0 / count, (bf16_t*)tn, tn_pitch, scratch, Cout, Cin);
+  hipLaunchKernelGGL(fold_wf_kernel, dim3(Cin), dim3(256), 0, st, (const bf16_t*)w, k1, k2, s1, scratch, 1.0 / count, (bf16_t*)wf, wf_pitch, cn, Cout, Cin);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

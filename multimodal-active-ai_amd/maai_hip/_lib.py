@@ -89,7 +89,10 @@ SIGNATURES = {
     "maai_sgd_step_multi": (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
     "maai_fold_s2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_fold_dw": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
-    "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "maai_gram": (c_i, [c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "maai_conv_dfold_rows": (c_ll, [c_ll]),
+    "maai_conv_dfold": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p]),
     "maai_comm_create": (c_i, [c_i, c_i, c_ll, c_p]),
     "maai_comm_handle": (c_i, [c_p, c_p]),
     "maai_comm_attach": (c_i, [c_p, c_i, c_p]),

@@ -239,13 +239,15 @@ _FUSE = {"max_cin": int(os.environ.get("MAAI_FUSE_MAX_CIN", "0")),
          "nograd_min_cin": int(os.environ.get("MAAI_FUSE_NOGRAD_MIN_CIN", "128"))}
 
 
-def _fusable(conv, form, keep=True):
+def _fusable(conv, form, keep=True, fold=False):
+    """``fold``: the unit's backward will be the folded one (``_FOLD``), which reads neither the raw output nor recomputes it —
+    the forward may then take the recompute form (statistics-only launch + BatchNorm-epilogue launch) with gradients too."""
     if not (form == "fwd" and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
             and conv.out_channels >= 4 * conv.in_channels):
         return False
     if conv.in_channels <= _FUSE["max_cin"]:
         return True
-    return (not keep) and _FUSE["nograd_min_cin"] <= conv.in_channels <= _FUSE["nograd_max_cin"]
+    return (not keep or fold) and _FUSE["nograd_min_cin"] <= conv.in_channels <= _FUSE["nograd_max_cin"]
 
 
 def _bn_training(bn):
@@ -577,7 +579,13 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     pad_w = pad if kw > 1 else 0
     # (a "light" forward — the first pass of a recomputed block — keeps its records for their statistics only: it takes the
     #  forms of a forward without a backward)
-    fused = _fusable(conv, form, keep and not light) and not defer and branch is None and given is None
+    # (a unit whose backward is folded keeps no raw output: with gradients it takes the recompute form as well — where the
+    #  streaming kernel runs both launches, the input is a stored tensor and the BatchNorm takes batch statistics)
+    fold_fwd = (_FOLD["enabled"] and _FOLD["fwd"] and keep and not light and training and dtype == torch.bfloat16 and form == "fwd"
+                and not isinstance(x, K.Lazy) and K.conv_bn_act_fast(conv, x.shape[0], x.shape[1], x.shape[2], dtype, lazy=True)
+                and "MAAI_CONV_PWS" not in os.environ and _FUSE["max_cin"] == 0)
+    fused = _fusable(conv, form, keep and not light, fold=fold_fwd) and not defer and branch is None and given is None
+    fold_fwd = fold_fwd and fused
     rows_out = (x.shape[0] * ((x.shape[1] + 2 * pad - kh) // stride + 1) * ((x.shape[2] + 2 * pad_w - kw) // stride + 1))
     eval_ok = (given is None and not training and not keep and not defer and branch is None and _EVAL_FUSE["enabled"]
                and wq.shape[0] % 64 == 0)
@@ -617,7 +625,9 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     y = None
     # chained block boundary: this convolution is not run here (training: only its statistics are taken) — the next block's
     # first convolution recomputes it inside the launch that joins it with the shortcut
-    chain = (lazy_out and (not keep or light) and not fused and not eval_fused and not defer and given is None and form == "fwd"
+    # (with gradients too where the unit's backward is folded: it reads neither the raw output nor recomputes it)
+    fold_chain = _FOLD["enabled"] and _FOLD["fwd"] and keep and training and dtype == torch.bfloat16 and _FUSE["max_cin"] == 0
+    chain = (lazy_out and (not keep or light or fold_chain) and not fused and not eval_fused and not defer and given is None and form == "fwd"
              and (residual is not None or branch is not None) and _chain_ok(conv, x, dtype))
     if given is not None:
         training = given.training
@@ -670,14 +680,18 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         branch = branch[0]   # the shortcut branch, finalised by the same exchange (_drive_pair)
     xb = side["joined"] if (side is not None and isinstance(x, K.Lazy) and x.b is not None) else x  # what the backward reads
     if fused:
-        out = K.conv2d_bn_act(x, wq, scale, shift, residual, relu)
+        fbits = None
+        if fold_fwd and relu and residual is not None and _DGRAD_REDUCE["enabled"] and _DGRAD_REDUCE["bits"]:
+            out, fbits = K.conv2d_bn_act(x, wq, scale, shift, residual, relu, want_bits=True)   # the mask the backward multiplies by
+        else:
+            out = K.conv2d_bn_act(x, wq, scale, shift, residual, relu)
         if not keep:
             return out, None
         r = _Rec()
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused, r.shift, r.bits, r.fold = (x.shape[1], x.shape[2]), True, shift, None, None
+        r.in_hw, r.fused, r.shift, r.bits, r.fold = (x.shape[1], x.shape[2]), True, shift, fbits, None
         return out, r
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
@@ -776,7 +790,9 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
         if accumulate:
             raise MaaiError("conv_dgrad: accumulate needs an output tensor")
     incr = bool(sum_increment and accumulate)
-    fuse = below is not None and _DGRAD_REDUCE["enabled"] and (not empty or incr) and below.y is not None
+    # (a unit below whose BatchNorm backward is folded through its convolution wants sum(g) only: its raw output stays unread)
+    sum_only = below is not None and below.has_res and _fold_static(below)
+    fuse = below is not None and _DGRAD_REDUCE["enabled"] and (not empty or incr) and (below.y is not None or sum_only)
     from_y = False
     relu_mask = materialise(relu_mask)
     if below is not None:
@@ -814,7 +830,7 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
     slab = torch.empty((sum(rows), 2, cin), dtype=torch.float32, device=dy.device)
     r0 = 0
     for (wq, pad_h, pad_w, grid, off), nr in zip(launches, rows):
-        K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], below.y, _reduce_mean(below),
+        K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], None if sum_only else below.y, _reduce_mean(below),
                               below.scale if from_y else None, below.shift if from_y else None, relu_mask,
                               grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate,
                               mask_bits=use_bits, axf=axf, sum_increment=incr)
@@ -847,22 +863,38 @@ def _grad_to_reference(rec, dw):
 # Arithmetic: exact in real numbers; in bf16 storage y is never rounded (the unfolded path rounds it once), the folded
 # weights k1*W and W^T diag(k3) W are rounded to bf16 once each.  Pinned against the fp64 oracle per block
 # (tests/test_gpu_fold.py) — not bit-identical to the unfolded path.  MAAI_FOLD=0 turns it off.
-_FOLD = {"enabled": os.environ.get("MAAI_FOLD", "1") != "0"}
+# MAAI_FOLD_FWD=0: the folded units' FORWARD stays a stored-output launch (only the backward changes).
+_FOLD = {"enabled": os.environ.get("MAAI_FOLD", "1") != "0", "fwd": os.environ.get("MAAI_FOLD_FWD", "1") != "0"}
 
 
-def set_fold(flag):
+def set_fold(flag, fwd=None):
     _FOLD["enabled"] = bool(flag)
+    if fwd is not None:
+        _FOLD["fwd"] = bool(fwd)
 
 
 def _fold_applies(rec, dout):
-    if not (_FOLD["enabled"] and rec is not None and dout is not None and dout.dtype == torch.bfloat16 and rec.training and rec.form == "fwd"
-            and rec.k == 1 and rec.stride == 1 and rec.pad == 0 and not rec.fused):
+    return dout is not None and dout.dtype == torch.bfloat16 and _fold_static(rec)
+
+
+def _fold_static(rec):
+    """Will ``rec``'s backward be the folded one?  (everything ``_fold_applies`` asks, but the gradient's dtype: the units
+    that hand this unit its gradient ask, to leave its raw output unread)"""
+    if not (_FOLD["enabled"] and rec is not None and rec.training and rec.form == "fwd"
+            and rec.k == 1 and rec.stride == 1 and rec.pad == 0):
+        return False
+    lazy = isinstance(rec.x, K.Lazy)
+    xt = rec.x.y if lazy else rec.x
+    if xt is None or xt.dtype != torch.bfloat16:
         return False
     w = rec.conv.weight
     if not (w.shape[0] >= 2 * w.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 64 == 0):
         return False
-    # (phase 1: the input is a stored tensor — layer 1's conv3 takes a normalise-on-load input and has its own fused backward)
-    return not isinstance(rec.x, K.Lazy)
+    if lazy:
+        # a normalise-on-load input (layer 1: conv3 of the bottlenecks, layer1.0's projection shortcut): the Gram kernel and the
+        # weight gradient form it on load, the data gradient is csrc/conv_dfold.hip's (64 -> 256) or works on a materialised copy
+        return rec.x.b is None and rec.x.pre is None and w.shape[1] in K.GRAM_CHANNELS
+    return True
 
 
 class _Fold(object):
@@ -1030,16 +1062,30 @@ def _unit_bwd_folded(rec, g, grads, dtype, k1, k2, k3, need_dx, dx_out, accumula
     cout, cin = w.shape[0], w.shape[1]
     wq = w_fwd(w, dtype).reshape(cout, cin)
     x = rec.x
-    sx = K.bn_act_bwd_reduce(x, None, None, None, False)     # colsum(x) (fp64; the second half of the vector is unused)
+    npos = None
+    if cin in K.GRAM_CHANNELS:
+        gram, sx, npos = K.gram(x)             # Gram = x^T x, colsum(x) and the count of x > 0 in one pass over x (csrc/gram.hip)
+    else:
+        xm = materialise(x)
+        sx = K.bn_act_bwd_reduce(xm, None, None, None, False)
+        gram = K.conv2d_wgrad(xm, xm, 1, 1, 1, 0, 0).reshape(cin, cin) if w.requires_grad else None
     if w.requires_grad:
-        gram = K.conv2d_wgrad(x, x, 1, 1, 1, 0, 0).reshape(cin, cin)   # Gram = x^T x: a weight-gradient launch of x against itself
         dw = K.fold_dw(wq, f.g1, gram, sx, k1, k2, k3)
         grads[id(w)] = dw.reshape(cout, cin, 1, 1)
     rec.fold = None
     if not need_dx:
         return None, None
-    npix = x.numel() // cin      # (the LOCAL pixel count: s1 and sx are this rank's sums)
-    wf, tn, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix)
+    xt = x.y if isinstance(x, K.Lazy) else x
+    npix = xt.numel() // cin     # (the LOCAL pixel count: s1 and sx are this rank's sums)
+    if (isinstance(x, K.Lazy) and (cout, cin) == (256, 64) and below is not None and below.y is x.y and below.relu and not below.has_res
+            and not below.fused and x.relu and relu_mask is None and _DGRAD_REDUCE["enabled"] and (dx_out is None) == (not accumulate)):
+        # layer 1: [g | a2] against the concatenated folded weights in ONE launch, a2 formed on load from the unit below's raw
+        # output, that unit's mask and BatchNorm-backward sums in the epilogue (csrc/conv_dfold.hip)
+        wcat, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, cat=True, npos=npos)
+        dx, slab = K.conv_dfold(g, x.y, wcat, cn, _reduce_mean(below), below.scale, below.shift, dx=dx_out if accumulate else None)
+        return dx, K.reduce_partials(slab)
+    x = materialise(x)
+    wf, tn, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, npos=npos)
     # dx = g (k1 W) - x (W^T diag(k3) W) - k2 W: the short term first (K = Cin, a pointwise launch whose epilogue adds the
     # constant and — shortcut units — what is already in dx), then the long one accumulates onto it with the mask and the
     # BatchNorm-backward sums of the unit below in its epilogue
@@ -1205,7 +1251,7 @@ def _backbone_fwd(resnet, x, dtype, keep):
         # (block recompute: this forward's activations are dropped and rebuilt, so it runs with the no-backward policy)
         ckpt = ckpt_on and stages[i] in _RECOMPUTE["layers"]
         out, recs, xin, xin_bits = _block_fwd(blk, out, dtype, keep, lazy_out=lazy_out, pol_keep=keep and not ckpt)
-        if prev3 is not None:
+        if prev3 is not None and prev3.out is None:
             prev3.out, prev3.bits = xin, xin_bits   # the join this block's conv1 formed IS the previous block's output
         prev3 = recs[2] if (lazy_out and keep) else None
         if ckpt:
@@ -1255,6 +1301,7 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
         d, s = unit_bwd(r3, dout, grads, dtype, below=r2 if r2 is not None else r1, presums=presums)
     if r2 is not None:
         d, s = unit_bwd(r2, d, grads, dtype, below=r1, presums=s)
+    kdc = kd if (rd is not None and rd.fold is not None) else None   # a folded shortcut unit: its coefficients are already there
     if rd is not None:
         # dx = dgrad(conv1) (dense) then += dgrad(downsample) (strided scatter, accumulate + mask epilogue)
         # (mask both: pixels the strided scatter never touches keep the first, already masked, value;
@@ -1265,7 +1312,7 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
             # stride-2 shortcut: the dense conv1 pass reduces the sums of what it stores, the strided pass those of what
             # it adds on the pixels it touches (sum_increment) — together the sums of the final gradient
             dx, sa = unit_bwd(r1, d, grads, dtype, below=prev, presums=s)
-            dx, sb = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd, sum_increment=True)
+            dx, sb = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd, sum_increment=True, coeffs=kdc)
             sp = sa + sb if (sa is not None and sb is not None) else None
             if sp is None and (sa is not None or sb is not None):
                 raise MaaiError("block_bwd: the two passes of a strided shortcut must both reduce or both not")
@@ -1275,9 +1322,9 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
             if prev is not None and kd_fused:
                 dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, coeffs=kd)
             elif prev is not None:
-                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd)
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, below=prev, dy=dyd, coeffs=kdc)
             else:
-                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=in_mask(), dy=dyd)
+                dx, sp = unit_bwd(rd, dout, grads, dtype, dx_out=dx, accumulate=True, relu_mask=in_mask(), dy=dyd, coeffs=kdc)
     else:
         # identity shortcut: dx = dout + dgrad(conv1), accumulated in place in the conv epilogue
         if prev is not None:

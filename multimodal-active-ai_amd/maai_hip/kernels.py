@@ -323,8 +323,11 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     ``axf = (y_raw, k1, k2, k3, dy_out)``: x is dz and the GEMM operand is k1*dz - k2 - k3*y_raw (BatchNorm-backward
     apply of the layer above), formed while staging; dy_out (or None) receives it.  Pointwise bf16 layers only."""
     _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask)
-    if x.dtype != w.dtype or lower_y.dtype != out.dtype or lower_y.shape != out.shape:
+    if x.dtype != w.dtype or (lower_y is not None and (lower_y.dtype != out.dtype or lower_y.shape != out.shape)):
         raise MaaiError("conv2d_store_reduce: operand dtype / shape mismatch")
+    if lower_y is None and relu_mask is None:
+        # (the unit below folds its BatchNorm backward through its convolution: only sum(g) is wanted, the mask is its own)
+        raise MaaiError("conv2d_store_reduce: without the lower layer's raw output the mask must be given (first sum only)")
     if mask_bits:
         if relu_mask is None or relu_mask.dtype != torch.uint8 or relu_mask.numel() * 8 != out.numel() or out.dtype != torch.bfloat16:
             raise MaaiError("conv2d_store_reduce: the 1-bit mask must be uint8 [numel/8] over a bf16 output")
@@ -332,7 +335,7 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
         raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
     d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
     epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
-                       None if shift is None else shift.data_ptr(), lower_y.data_ptr(), 1 if mask_bits else 0,
+                       None if shift is None else shift.data_ptr(), None if lower_y is None else lower_y.data_ptr(), 1 if mask_bits else 0,
                        1 if (sum_increment and accumulate) else 0)
     if axf is not None:
         ya, k1, k2, k3, dyo = axf
@@ -349,7 +352,7 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[red] M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
                 es * (x.numel() * (1 if axf is None else (3 if axf[4] is not None else 2)) + w.numel()
-                      + m * d.Cout * (2 + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
+                      + m * d.Cout * ((1 if lower_y is None else 2) + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
                 + (m * d.Cout // 8 if mask_bits else 0), es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
               "maai_conv2d_igemm_fused")
@@ -433,13 +436,14 @@ def conv2d_chained(xf, w, stats=False, join_bits=False, keep_y=False):
     return _conv2d_chained(xf, w, stats, join_bits, keep_y)
 
 
-def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=0, pad_w=0):
+def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=0, pad_w=0, want_bits=False):
     """out = act(conv(x, w)*scale + shift (+ residual)) in the conv epilogue (pass 2 of the fused unit; every unit of an
     inference forward with frozen statistics).  ``x`` may be a single-tensor ``Lazy`` where the streaming kernel takes the
-    shape (``conv_bn_act_fast(..., lazy=True)``): formed on load AND normalised on store in one launch."""
+    shape (``conv_bn_act_fast(..., lazy=True)``): formed on load AND normalised on store in one launch.
+    ``want_bits`` (ReLU units on the streaming kernel, tensor input): also the 1-bit mask of out -> (out, bits)."""
     if isinstance(x, Lazy):
-        if x.b is not None or x.pre is not None:
-            raise MaaiError("conv2d_bn_act: a single-tensor Lazy")
+        if x.b is not None or x.pre is not None or want_bits:
+            raise MaaiError("conv2d_bn_act: a single-tensor Lazy (and no mask output)")
         xt = x.y
         _gpu(xt, w, scale, shift, residual)
         d = make_desc(xt, w, stride, pad_h, pad_w)
@@ -458,6 +462,19 @@ def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad_h=
     _gpu(x, w, scale, shift, residual)
     d = make_desc(x, w, stride, pad_h, pad_w)
     out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=x.dtype, device=x.device)
+    if want_bits:
+        if not relu or x.dtype != torch.bfloat16:
+            raise MaaiError("conv2d_bn_act: the mask output belongs to a bf16 ReLU unit")
+        bits = torch.empty((out.numel() // 8,), dtype=torch.uint8, device=x.device)
+        epi = ConvEpilogue(EPI_BN_ACT, 1, scale.data_ptr(), shift.data_ptr(), None, None if residual is None else residual.data_ptr())
+        epi.x_bits = bits.data_ptr()
+        m = d.N * d.OHg * d.OWg
+        nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[epi2 bits] M%d Cin%d Cout%d k%dx%d" % (m, d.Cin, d.Cout, d.KH, d.KW)
+        with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin, 2 * (x.numel() + w.numel() + m * d.Cout * (2 if residual is not None else 1)) + bits.numel(),
+                    2 * (x.numel() + m * d.Cout)):
+            check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), None, None, C.byref(epi), BF16, _stream()),
+                  "maai_conv2d_igemm_fused")
+        return out, bits
     _conv_fused(x, w, stride, pad_h, pad_w, EPI_BN_ACT, out, None, scale, shift, None, residual, relu)
     return out
 
@@ -752,21 +769,77 @@ def fold_dw(wq, g1, gram, sx, k1, k2, k3):
     return dw
 
 
-def fold_dgrad_weights(wq, k1, k2, k3, s1, sx, count):
+def fold_dgrad_weights(wq, k1, k2, k3, s1, sx, count, cat=False, npos=None):
     """(wf [Cin,1,1,Cout] bf16 = k1*W in data-gradient form, tn [Cin,1,1,Cin] bf16 = -(W^T diag(k3) W), cn [Cin] fp32 = -(k2 W)
     minus the pixel mean of what rounding wf and tn adds to dx: ``s1`` = sum g [Cout], ``sx`` = colsum x [Cin] (fp64) over
-    ``count`` pixels)"""
-    _gpu(wq, k1, k2, k3, s1, sx)
+    ``count`` pixels; ``npos`` [Cin] fp64 = pixels with x_k > 0, from ``gram``: the diagonal of tn is compensated exactly).
+    ``cat``: ONE matrix Wcat [Cin,1,1,Cout+Cin] = [wf | tn] (what ``conv_dfold`` multiplies by) -> (wcat, cn)."""
+    _gpu(wq, k1, k2, k3, s1, sx, npos)
     cout, cin = wq.shape[0], wq.numel() // wq.shape[0]
-    if s1.dtype != torch.float64 or sx.dtype != torch.float64 or s1.numel() < cout or sx.numel() < cin:
+    if s1.dtype != torch.float64 or sx.dtype != torch.float64 or s1.numel() < cout or sx.numel() < cin or \
+            (npos is not None and (npos.dtype != torch.float64 or npos.numel() < cin)):
         raise MaaiError("fold_dgrad_weights: fp64 s1 [Cout], sx [Cin]")
-    wf = torch.empty((cin, 1, 1, cout), dtype=torch.bfloat16, device=wq.device)
-    tn = torch.empty((cin, 1, 1, cin), dtype=torch.bfloat16, device=wq.device)
     cn = torch.empty(cin, dtype=torch.float32, device=wq.device)
     scratch = torch.empty(cin, dtype=torch.float32, device=wq.device)
-    check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), float(count), _p(wf), _p(tn), _p(cn), _p(scratch),
-                                  cout, cin, _stream()), "maai_fold_dgrad_w")
+    if cat:
+        wcat = torch.empty((cin, 1, 1, cout + cin), dtype=torch.bfloat16, device=wq.device)
+        tnp = C.c_void_p(wcat.data_ptr() + 2 * cout)
+        check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), _p(npos), float(count), _p(wcat), cout + cin, tnp, cout + cin,
+                                      _p(cn), _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
+        return wcat, cn
+    wf = torch.empty((cin, 1, 1, cout), dtype=torch.bfloat16, device=wq.device)
+    tn = torch.empty((cin, 1, 1, cin), dtype=torch.bfloat16, device=wq.device)
+    check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), _p(npos), float(count), _p(wf), cout, _p(tn), cin, _p(cn),
+                                  _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
     return wf, tn, cn
+
+
+GRAM_CHANNELS = (64, 128, 256, 512)
+
+
+def gram(x):
+    """(Gram = x^T x [C,C] fp32, sx = colsum(x) [C] fp64, npos [C] fp64 = rows with x > 0) of an activation [.., C] bf16 — a tensor or a single-tensor ``Lazy``
+    (formed on load).  csrc/gram.hip; accumulated with atomics: last-bit run-to-run differences, like every weight gradient."""
+    xs = xt = None
+    x_relu = 0
+    if isinstance(x, Lazy):
+        if x.b is not None or x.pre is not None:
+            raise MaaiError("gram: a tensor or a single-tensor Lazy")
+        _gpu(x.scale, x.shift)
+        xs, xt, x_relu, x = x.scale, x.shift, 1 if x.relu else 0, x.y
+    _gpu(x)
+    c = x.shape[-1]
+    if x.dtype != torch.bfloat16 or c not in GRAM_CHANNELS:
+        raise MaaiError("gram: bf16 activations with 64, 128, 256 or 512 channels")
+    m = x.numel() // c
+    g = torch.zeros((c, c), dtype=torch.float32, device=x.device)
+    sv = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
+    sx, npos = sv[:c], sv[c:]
+    with _timed("gram" if not DETAIL[0] else "gram M%d C%d" % (m, c), 2.0 * m * c * c, 2.0 * x.numel(), 0.0):
+        check(lib().maai_gram(_p(x), m, c, _p(xs), _p(xt), x_relu, _p(g), _p(sx), _p(npos), _stream()), "maai_gram")
+    return g, sx, npos
+
+
+def conv_dfold(g, y2, wcat, cn, mean2, s2, t2, dx=None):
+    """The folded 64 -> 256 unit's data gradient (csrc/conv_dfold.hip): dx = ([g | relu(bn2(y2))] Wcat^T + cn) * [a2 > 0] with
+    the unit below's BatchNorm-backward partial sums -> (dx [.., 64], slab [rows, 2, 64]).  ``dx`` given: += in place."""
+    _gpu(g, y2, wcat, cn, mean2, s2, t2, dx)
+    if not (g.dtype == y2.dtype == wcat.dtype == torch.bfloat16) or g.shape[-1] != 256 or y2.shape[-1] != 64 or \
+            y2.shape[:-1] != g.shape[:-1] or tuple(wcat.shape) != (64, 1, 1, 320):
+        raise MaaiError("conv_dfold: g [..,256], y2 [..,64] and Wcat [64,1,1,320] in bf16")
+    m = g.numel() // 256
+    acc = dx is not None
+    if acc and (dx.shape != y2.shape or dx.dtype != y2.dtype or not dx.is_contiguous()):
+        raise MaaiError("conv_dfold: dx must match y2")
+    if not acc:
+        dx = torch.empty_like(y2)
+    rows = int(lib().maai_conv_dfold_rows(m))
+    slab = torch.empty((rows, 2, 64), dtype=torch.float32, device=g.device)
+    nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[dfold] M%d Cin320 Cout64 k1x1 s1 os1 acc%d" % (m, 1 if acc else 0)
+    with _timed(nm, 2.0 * m * 320 * 64, 2 * (g.numel() + (3 if acc else 2) * y2.numel() + wcat.numel()), 2 * (g.numel() + y2.numel())):
+        check(lib().maai_conv_dfold(_p(g), _p(y2), _p(wcat), _p(cn), _p(mean2), _p(s2), _p(t2), _p(dx), _p(slab), m, 1 if acc else 0,
+                                    _stream()), "maai_conv_dfold")
+    return dx, slab
 
 
 # ----------------------------------------------------------------------------

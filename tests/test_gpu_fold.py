@@ -6,8 +6,9 @@ BatchNorm-backward apply pass and without reading the raw convolution output y â
 
 The folded path is NOT bit-identical to the unfolded one (y is never rounded to bf16; the folded weights are): it is pinned
 here against an fp64 torch-autograd evaluation of the same unit on the same bf16 inputs, with the unfolded HIP path beside
-it as the yardstick: the folded gradients must be at least as close to fp64 as 1.5 x the unfolded path's error + 2^-9 of
-the gradient's scale (the bf16 storage rounding of the result itself)."""
+it as the yardstick: the folded gradients must be at least as close to fp64 as 1.5 x the unfolded path's error + 2^-8 of
+the gradient's scale (the bf16 storage rounding of the result itself); measured: dW and dgamma 100-1000 x closer (3e-6 vs 3e-3),
+dx equal (4-6e-3), the unit below's BatchNorm-backward sums 2-4 x further (see the comment at the assertion)."""
 import pytest
 import torch
 
@@ -50,19 +51,22 @@ def test_fold_algebra_kernels_match_fp64(E, cout, cin):
     ref = k1.double()[:, None] * g1.double() - k2.double()[:, None] * sx[:cin][None, :] - k3.double()[:, None] * (wd @ gram.double())
     assert (dw.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
     npix = 5000.0
-    wf, tn, cn = K.fold_dgrad_weights(w, k1, k2, k3, s1, sx, npix)
+    npos = (torch.rand(cin, generator=g, dtype=torch.float64) * 3000 + 1000).cuda()
+    wf, tn, cn = K.fold_dgrad_weights(w, k1, k2, k3, s1, sx, npix, npos=npos)
     assert tuple(wf.shape) == (cin, 1, 1, cout) and tuple(tn.shape) == (cin, 1, 1, cin)
     ref_wf = (k1[:, None] * w.float()).t().contiguous()
     assert torch.equal(wf.reshape(cin, cout), ref_wf.bfloat16())
     ref_t = -(wd.t() @ (k3.double()[:, None] * wd))
     assert (tn.reshape(cin, cin).double() - ref_t.t()).abs().max() <= 2.0 ** -8 * ref_t.abs().max()   # bf16 result: half an ulp = 2^-9
     # the constant: -(k2 W) minus the pixel mean of what the two roundings add to dx[:, k]
-    comp = ((wf.reshape(cin, cout).double() - ref_wf.double()) @ s1 + (tn.reshape(cin, cin).double() - ref_t.t()) @ sx[:cin]) / npix
+    dt = tn.reshape(cin, cin).double() - ref_t.t()
+    off = dt - torch.diag(torch.diagonal(dt))
+    comp = ((wf.reshape(cin, cout).double() - ref_wf.double()) @ s1 + off @ sx[:cin]) / npix + torch.diagonal(dt) * sx[:cin] / npos
     ref = -(k2.double()[None, :] @ wd).reshape(cin) - comp
     assert (cn.double() - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-9
 
 
-def _unit(E, n, h, w_, cin, cout, seed):
+def _unit(E, n, h, w_, cin, cout, seed, lazy=False):
     """One conv3-like unit with a conv2-like unit below it, on random bf16 tensors: returns everything the engine's unit_bwd
     needs and the fp64 reference gradients."""
     from maai_hip import kernels as K
@@ -80,8 +84,10 @@ def _unit(E, n, h, w_, cin, cout, seed):
     x1 = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()      # conv2's input (a post-ReLU tensor in the net)
     x1 = torch.relu(x1)
     dtype = torch.bfloat16
-    a2, r2 = E.unit_fwd(x1, conv2, bn2, True, None, dtype, True)
+    # ``lazy``: conv2's activation is never stored â€” conv3 (and its backward) form it on load, as in layer 1
+    a2, r2 = E.unit_fwd(x1, conv2, bn2, True, None, dtype, True, lazy_out=lazy)
     out, r3 = E.unit_fwd(a2, conv3, bn3, True, None, dtype, True)
+    a2 = E.materialise(a2)
     gout = torch.randn(out.shape, generator=g).cuda().bfloat16()
     gout = gout + 0.3                                                   # a gradient with a mean: k2 matters
     return dict(conv2=conv2, bn2=bn2, conv3=conv3, bn3=bn3, x1=x1, a2=a2, r2=r2, r3=r3, out=out, gout=gout)
@@ -114,11 +120,14 @@ def _run(E, u, fold):
     return dx, grads[id(u["conv3"].weight)], grads[id(u["bn3"].weight)], grads[id(u["bn3"].bias)], sums
 
 
-@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 512), (8, 14, 14, 256, 1024), (8, 7, 7, 512, 2048), (2, 33, 35, 64, 256)],
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 512, 0), (8, 14, 14, 256, 1024, 0), (8, 7, 7, 512, 2048, 0), (2, 33, 35, 64, 256, 0),
+                                   (2, 33, 35, 64, 256, 1), (4, 56, 56, 64, 256, 1), (2, 30, 30, 128, 512, 1)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_folded_unit_backward_against_fp64(E, shape):
-    n, h, w_, cin, cout = shape
-    u = _unit(E, n, h, w_, cin, cout, seed=sum(shape))
+    """shape[5] = 1: the unit's input is a normalise-on-load activation (layer 1): Gram / G1 form it on load; 64 -> 256 takes the
+    one-launch data gradient of csrc/conv_dfold.hip, other shapes a materialised copy."""
+    n, h, w_, cin, cout, lazy = shape
+    u = _unit(E, n, h, w_, cin, cout, seed=sum(shape), lazy=bool(lazy))
     assert not isinstance(u["r3"].x, type(None))
     ref = _reference(u)
     assert E._fold_applies(u["r3"], u["gout"])
@@ -132,6 +141,15 @@ def test_folded_unit_backward_against_fp64(E, shape):
         ef, eu = (f - r).abs().max().item() / scale, (un - r).abs().max().item() / scale
         cos = torch.nn.functional.cosine_similarity(f, r, dim=0).item()
         print("%s %s: folded %.3e  unfolded %.3e  cos %.6f" % ("x".join(map(str, shape)), nm, ef, eu, cos))
+        if nm == "sums below":
+            # The one quantity the folded path gives up accuracy on (measured 0.4-1.3e-2 of its largest entry against the
+            # unfolded path's 0.2-0.4e-2).  These sums cancel almost completely (sum_p dy = 0 before the ReLU mask), and the
+            # bf16 rounding of the folded WEIGHTS perturbs dx coherently over the pixels where the rounding of dy (unfolded)
+            # is independent per element; the pixel MEAN of that perturbation is taken out of the constant (fold_wf_kernel),
+            # what is left is its correlation with the mask.
+            assert cos > 0.999, (nm, cos)
+            assert ef <= 4.0 * eu + 2.0 ** -8, (nm, ef, eu)
+            continue
         assert cos > 0.9999, (nm, cos)
         assert ef <= 1.5 * eu + 2.0 ** -8, (nm, ef, eu)
 
@@ -171,3 +189,107 @@ def test_folded_unit_backward_in_a_projection_block(E):
             cos = torch.nn.functional.cosine_similarity(f, un, dim=0).item()
             assert cos > 0.9995, (inp, planes, nm, cos)
             assert abs(f.norm().item() / un.norm().item() - 1) < 1e-2, (inp, planes, nm)
+
+
+@pytest.mark.parametrize("res", [False, True])
+@pytest.mark.parametrize("shape", [(2, 30, 30, 128, 512), (4, 28, 28, 256, 1024), (1, 33, 35, 64, 256)], ids=lambda s: "x".join(map(str, s)))
+def test_bn_relu_epilogue_mask_output_equals_the_pass(E, shape, res):
+    """The training forward of a folded unit (statistics-only launch + BatchNorm/shortcut/ReLU epilogue launch of the streaming
+    kernel, csrc/conv_pws.hip EMODE 2 + BITS) hands the backward the 1-bit ReLU mask of its output: output and mask are
+    bit-identical to launch + maai_bn_act_fwd_mask (resnet.py:118-133)."""
+    from maai_hip import kernels as K
+    n, h, w_, cin, cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + int(res))
+    x = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda().bfloat16()
+    s = (torch.rand(cout, generator=g) + 0.5).cuda()
+    t = (torch.randn(cout, generator=g) * 0.5).cuda()
+    r = torch.randn(n, h, w_, cout, generator=g).cuda().bfloat16() if res else None
+    out, bits = K.conv2d_bn_act(x, w, s, t, r, True, want_bits=True)
+    ref, rbits = K.bn_act_fwd(K.conv2d(x, w), s, t, r, True, want_bits=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(bits, rbits)
+    assert 0.2 < (out > 0).float().mean().item() < 0.8
+
+
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 512, 0), (4, 28, 28, 128, 512, 1), (8, 14, 14, 256, 1024, 1), (2, 7, 7, 512, 2048, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_sum_only_data_gradient_epilogue(E, shape):
+    """The data-gradient epilogue that reduces the BatchNorm-backward sums of the unit BELOW (MAAI_EPI_DGRAD_REDUCE) without
+    that unit's raw output â€” a folded unit wants sum(g) only: same stored gradient, same first sum, ring and ping-pong kernels,
+    store and accumulate."""
+    from maai_hip import kernels as K
+    n, h, w_, cin, cout, acc = shape     # a conv1-like data gradient: dy [.., cin] -> dx [.., cout] (the block input's channels)
+    g = torch.Generator().manual_seed(sum(shape))
+    dy = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    wd = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda().bfloat16()
+    y = torch.randn(n, h, w_, cout, generator=g).cuda().bfloat16()
+    mean = torch.randn(cout, generator=g).cuda()
+    bits = (torch.rand(n * h * w_ * cout // 8, generator=g) * 256).to(torch.uint8).cuda()
+    prev = torch.randn(n, h, w_, cout, generator=g).cuda().bfloat16()
+    rows = K.conv2d_stats_rows(dy, wd, 1, 0, 0)
+    outs = []
+    for lower in (y, None):
+        out = prev.clone() if acc else torch.empty_like(prev)
+        slab = torch.empty((rows, 2, cout), dtype=torch.float32, device="cuda")
+        K.conv2d_store_reduce(dy, wd, 1, 0, 0, out, slab, lower, mean, None, None, bits, accumulate=bool(acc), mask_bits=True)
+        outs.append((out, K.reduce_partials(slab)))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1][:cout], outs[1][1][:cout])
+    ref = (outs[0][0].double()).sum((0, 1, 2))
+    assert (outs[1][1][:cout] - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("xf", [False, True])
+@pytest.mark.parametrize("m,c", [(5000, 64), (12544, 64), (3136, 128), (1000, 256), (777, 512), (64, 512)])
+def test_gram_kernel_against_fp64(E, m, c, xf):
+    """csrc/gram.hip: Gram = x^T x and colsum(x) of a [M, C] activation (tensor or normalise-on-load), ragged last tile."""
+    from maai_hip import kernels as K
+    g = torch.Generator().manual_seed(m + c + int(xf))
+    y = torch.randn(1, 1, m, c, generator=g).cuda().bfloat16()
+    if xf:
+        s_ = (torch.rand(c, generator=g) + 0.5).cuda()
+        t_ = (torch.randn(c, generator=g) * 0.5).cuda()
+        x = K.Lazy(y, s_, t_, True)
+        xm = E.materialise(x).double().reshape(m, c)
+    else:
+        x = y
+        xm = y.double().reshape(m, c)
+    gram, sx, npos = K.gram(x)
+    torch.cuda.synchronize()
+    assert torch.equal(npos, (xm > 0).double().sum(0))
+    ref = xm.t() @ xm
+    assert (gram.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
+    rs = xm.sum(0)
+    assert (sx - rs).abs().max() <= 2e-5 * rs.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("acc", [False, True])
+@pytest.mark.parametrize("m", [128, 1000, 12544])
+def test_dfold_kernel_against_fp64(E, m, acc):
+    """csrc/conv_dfold.hip on its own: dx = ([g | relu(bn2(y2))] Wcat^T + cn) * [a2 > 0] (+= previous), the unit below's partial
+    sums â€” against fp64 on the same bf16 operands."""
+    from maai_hip import kernels as K
+    g = torch.Generator().manual_seed(m + int(acc))
+    gg = torch.randn(1, 1, m, 256, generator=g).cuda().bfloat16()
+    y2 = torch.randn(1, 1, m, 64, generator=g).cuda().bfloat16()
+    wcat = (torch.randn(64, 1, 1, 320, generator=g) / 16).cuda().bfloat16()
+    cn = (torch.randn(64, generator=g) * 0.1).cuda()
+    s2 = (torch.rand(64, generator=g) + 0.5).cuda()
+    t2 = (torch.randn(64, generator=g) * 0.3).cuda()
+    mean2 = torch.randn(64, generator=g).cuda()
+    prev = torch.randn(1, 1, m, 64, generator=g).cuda().bfloat16()
+    dx, slab = K.conv_dfold(gg, y2, wcat, cn, mean2, s2, t2, dx=prev.clone() if acc else None)
+    sums = K.reduce_partials(slab)
+    torch.cuda.synchronize()
+    a2 = K.bn_act_fwd(y2, s2, t2, None, True).double().reshape(m, 64)
+    lin = torch.cat([gg.double().reshape(m, 256), a2], 1) @ wcat.double().reshape(64, 320).t() + cn.double()
+    if acc:
+        lin = lin.bfloat16().double() + prev.double().reshape(m, 64)   # (the kernel rounds acc + cn to bf16 before adding)
+    pos = (y2.float().reshape(m, 64) * s2 + t2) > 0
+    ref = lin * pos
+    got = dx.double().reshape(m, 64)
+    assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    rs = torch.cat([got.sum(0), (got * (y2.double().reshape(m, 64) - mean2.double())).sum(0)])
+    assert (sums - rs).abs().max() <= 1e-4 * rs.abs().max() + 1e-3

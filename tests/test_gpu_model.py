@@ -624,7 +624,8 @@ def test_normalise_on_load_is_bit_identical(mods, prec, arch, cm, shape):
             scale = gp.abs().max().item() + 1e-30
             assert (gf - gp).abs().max().item() <= (1e-1 if prec == "bf16" else 2e-4) * scale, (tag, n)
             assert torch.nn.functional.cosine_similarity(gf.flatten().double(), gp.flatten().double(), dim=0).item() > (0.99 if prec == "bf16" else 0.999999), (tag, n)
-    assert res["lazy"][2] < 0.9 * res["plain"][2], (res["lazy"][2], res["plain"][2])
+    # (0.97: the folded units keep no raw output in ANY of these modes, so "plain" is leaner than it was — round 3: 0.9)
+    assert res["lazy"][2] < 0.97 * res["plain"][2], (res["lazy"][2], res["plain"][2])
     assert res["join"][2] <= res["lazy"][2]
 
 
@@ -676,7 +677,7 @@ def test_block_recompute_matches_stored_activations(mods, prec, layers):
         finally:
             engine.set_recompute(False, (1, 2))
     assert torch.equal(res["stored"][0], res["recompute"][0])
-    assert res["recompute"][2] < (0.6 if 1 in layers else 0.9) * res["stored"][2], (res["recompute"][2], res["stored"][2])
+    assert res["recompute"][2] < (0.65 if 1 in layers else 0.9) * res["stored"][2], (res["recompute"][2], res["stored"][2])   # (stored: folded units keep no raw output)
     assert torch.equal(res["stored"][3], res["recompute"][3]) and res["stored"][4] == res["recompute"][4] == 1
     assert res["stored"][1].keys() == res["recompute"][1].keys()
     for n, gp in res["stored"][1].items():
