@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--recompute", action="store_true",
                     help="block recompute in the backward (fits --batch 512 = global 4096 on 8 GPUs in 288 GB; one extra forward)")
     ap.add_argument("--no-recompute", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the two forwards of a step one after the other (default at N = 1 without recompute: the no-grad view on a side "
+                         "HIP stream, BatchNorm buffers updated in program order after the join: engine.set_overlap_views)")
     args = ap.parse_args()
     if args.recompute and args.no_recompute:
         ap.error("--recompute and --no-recompute are contradictory")
@@ -299,6 +302,9 @@ def main():
         engine.set_recompute(True, rc_layers)
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
+    from maai_hip import engine as _engine
+    overlap = world == 1 and not args.recompute and not args.no_overlap and os.environ.get("MAAI_OVERLAP_VIEWS", "1") != "0"
+    _engine.set_overlap_views(overlap)
 
     def barrier():
         if world > 1:
@@ -333,7 +339,9 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
-    # one extra, untimed, instrumented step: per-kernel HIP-event durations on the launch stream
+    # one extra, untimed, instrumented step: per-kernel HIP-event durations on the launch stream — with the two forwards
+    # one after the other (overlapped, a launch's events also span the other stream's launches it shares the device with)
+    _engine.set_overlap_views(False)
     from maai_hip import kernels as K
     with K.profile() as prof:
         step()
@@ -429,7 +437,7 @@ def main():
                                    % (args.arch, args.img, args.img, args.batch, " with block recompute" if args.recompute else "",
                                       args.temperature, "configs[2] (global batch 4096)" if world * args.batch == 4096 else "configs[1] per GPU"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": losses[-1], "loss_first_timed_step": losses[0],
-                       "recompute": bool(args.recompute), "recompute_layers": rc_layers, "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                       "recompute": bool(args.recompute), "recompute_layers": rc_layers, "overlap_views": bool(overlap), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                        "peak_hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -165,6 +165,17 @@ typedef struct {
   int pre_relu;
   int pre_cin;
   void* pre_y_out;
+  /* two-source input (MAAI_EPI_DGRAD_REDUCE on pointwise stride-1 bf16 layers: the data gradient of a unit whose BatchNorm
+   * backward is folded through its convolution, see maai_fold_dgrad_w): input channels [0, cin1) are read from x (rows of
+   * cin1 elements), [cin1, Cin) from x2 (rows of Cin - cin1); both multiples of 64.  bias (nullable, [Cout]) is added to the
+   * accumulators before they are rounded and stored (also without x2). */
+  const void* x2;
+  int cin1;
+  const float* bias;
+  /* diag (nullable, [Cout]; with p1/p2 = the lower unit's scale/shift and t = its raw output): out[p][c] += diag[c] * a[p][c]
+   * with a = relu(r(t*scale + shift)), the lower unit's activation recomputed in the epilogue — T's diagonal of the folded
+   * data gradient in fp32 (maai_fold_dgrad_w, dg). */
+  const float* diag;
 } maai_conv_epilogue;
 int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, const void* w, void* y, float* stats_partial,
                             const void* relu_mask, const maai_conv_epilogue* epi, int dtype, void* stream);
@@ -223,6 +234,19 @@ int maai_bn_pack_stats(const double* sums, double count, float* packed, int C, v
 int maai_bn_finalize_gathered(const float* gathered, int world, long long row_stride, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, double* count_out, int C, void* stream);
+/* Deferred running-statistic updates: slots[i] = {running [n], stat_a [n], stat_b [n] or null, n, momentum}: running <-
+ * (1 - momentum)*running + momentum*stat_a, then the same with stat_b — maai_bn_finalize's arithmetic, applied for every layer
+ * in ONE launch after two forwards that ran concurrently (each wrote its (float)mean / (float)unbiased variance to scratch:
+ * maai_bn_finalize with momentum 1 on zeroed buffers).  slots: device memory. */
+typedef struct {
+  float* running;
+  const float* stat_a;
+  const float* stat_b;
+  long long n;
+  float momentum;
+  int reserved;
+} maai_bn_update_slot;
+int maai_bn_running_update_multi(const maai_bn_update_slot* slots, int nslots, void* stream);
 /* eval mode: scale/shift from running statistics */
 int maai_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* scale, float* shift, int C, void* stream);
@@ -325,18 +349,19 @@ int maai_ntxent_normalize_bwd(const float* z, const float* dz, const float* inv_
  *   maai_fold_dw:      dw[c,k] = k1[c] G1[c,k] - k2[c] sx[k] - k3[c] (W Gram)[c,k]  (= (k1*g - k2 - k3*y)^T x)
  *   maai_fold_dgrad_w: wf[k][c] = bf16(k1[c] W[c,k]), tn[k][j] = bf16(-(W^T diag(k3) W)[j,k]), cn[k] = -(k2 W)[k] - comp[k], so that
  *                      dx = g wf^T + x tn^T + cn                                    (= (k1*g - k2 - k3*y) W)
- *                      comp[k] = the mean, over the pixels output channel k's ReLU mask keeps, of what the bf16 rounding of the
- *                      folded weights adds to dx[:, k]: (s1 . (wf[k] - exact) + sum_{j != k} sx[j] (tn[k][j] - exact)) / count
- *                      + sx[k] (tn[k][k] - exact) / npos[k]  (s1 = sum g, sx = colsum x over `count` pixels, npos[k] = pixels with
- *                      x_k > 0, nullable -> count) — taken out of the constant so that this rounding error is zero-mean where it
- *                      counts; scratch: Cin floats.
+ *                      comp[k] = (s1 . (wf[k] - exact) + sx . (tn[k] - exact)) / count: the pixel mean of what the bf16 rounding
+ *                      of the folded weights adds to dx[:, k] (s1 = sum g, sx = colsum x over `count` pixels), taken out of the
+ *                      constant.  dg (nullable, [Cin] fp32): the DIAGONAL of -(W^T diag(k3) W) — a sum of squares, the one large
+ *                      entry per row, multiplying the very x[p][k] the ReLU mask and the unit below's BatchNorm-backward sums
+ *                      are made of — is then returned in fp32 and tn[k][k] = 0: the data-gradient launch adds dg[k]*x[p][k] in its
+ *                      epilogue (maai_conv_epilogue.diag / maai_conv_dfold).  scratch: Cin floats.
  * w: the bf16 kernel-layout weights [Cout][Cin]; g1, gram, dw fp32; s1, s2, sx fp64; k1..k3 as maai_bn_bwd_coeffs gives them.
  * ------------------------------------------------------------------------ */
 int maai_fold_s2(const void* w, const float* g1, const double* s1, const float* mean, double* s2, int Cout, int Cin, void* stream);
 int maai_fold_dw(const void* w, const float* g1, const float* gram, const double* sx, const float* k1, const float* k2,
                  const float* k3, float* dw, int Cout, int Cin, void* stream);
 int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const float* k3, const double* s1, const double* sx,
-                      const double* npos, double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* scratch, int Cout, int Cin,
+                      double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* dg, float* scratch, int Cout, int Cin,
                       void* stream);
 /* wf_pitch / tn_pitch: row pitches (elements) of wf [Cin rows] and tn [Cin rows]: Cout and Cin for two separate matrices, or
  * both Cout + Cin with tn = wf + Cout for the concatenated form Wcat [Cin][Cout + Cin] that maai_conv_dfold multiplies by.
@@ -345,14 +370,14 @@ int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const flo
  * the M rows of x [M][C] bf16 (C = 64, 128, 256, 512); xs / xt (nullable, [C]) + x_relu: x is act(raw*xs + xt) formed on load
  * (maai_bn_act_fwd arithmetic).
  * maai_conv_dfold (csrc/conv_dfold.hip): the folded unit's data gradient for the 64 -> 256 units of layer 1 in one launch —
- *   dx[M][64] = ([g | a2] Wcat^T + cn) * [a2 > 0],  a2 = relu(r(y2*s2 + t2)) formed on load from the raw y2 [M][64], g [M][256],
+ *   dx[M][64] = ([g | a2] Wcat^T + cn + dg*a2) * [a2 > 0],  a2 = relu(r(y2*s2 + t2)) formed on load from the raw y2 [M][64], g [M][256],
  *   (+)= when accumulate; slab [maai_conv_dfold_rows(M)][2][64]: partial sums of dx and dx*(y2 - mean2) (the unit below's
  *   BatchNorm backward). */
 int maai_gram(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* gram, double* sx, double* npos,
               void* stream);
 long long maai_conv_dfold_rows(long long M);
-int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* mean2, const float* s2, const float* t2,
-                    void* dx, float* slab, long long M, int accumulate, void* stream);
+int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* dg, const float* mean2, const float* s2,
+                    const float* t2, void* dx, float* slab, long long M, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------
  * Comm helper: one-shot direct all-gather over the xGMI mesh (symmetric buffers, peer-to-peer stores) — the

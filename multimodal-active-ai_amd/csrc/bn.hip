@@ -155,6 +155,38 @@ extern "C" int maai_bn_finalize(const double* sums, double count, const float* g
   return MAAI_OK;
 }
 
+// Deferred running-statistic updates (engine: the two forwards of a SimCLR step on two streams).  A forward that must not
+// touch the running buffers while another forward is in flight takes its (float)mean / (float)unbiased variance into
+// scratch (maai_bn_finalize with momentum 1 on a zeroed scratch buffer writes exactly those values); after the streams have
+// joined, ONE launch applies the updates of every layer in program order — stat_a (the earlier forward's) then stat_b —
+// with the arithmetic of maai_bn_finalize, (1 - momentum)*running + momentum*stat: the buffers end up bit-identical to two
+// forwards run one after the other.
+struct BnUpdateSlot {
+  float* running;
+  const float* stat_a;
+  const float* stat_b;   // nullable
+  long long n;
+  float momentum;
+  int pad;
+};
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const BnUpdateSlot* __restrict__ slots) {
+  const BnUpdateSlot s = slots[blockIdx.x];
+  for (long long i = threadIdx.x; i < s.n; i += 256) {
+    float r = s.running[i];
+    r = (1.f - s.momentum) * r + s.momentum * s.stat_a[i];
+    if (s.stat_b) r = (1.f - s.momentum) * r + s.momentum * s.stat_b[i];
+    s.running[i] = r;
+  }
+}
+static_assert(sizeof(BnUpdateSlot) == sizeof(maai_bn_update_slot), "slot layout");
+extern "C" int maai_bn_running_update_multi(const maai_bn_update_slot* slots, int nslots, void* stream) {
+  MAAI_CHECK_ARG(slots && nslots > 0, "bn_running_update_multi: bad arguments");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((unsigned)nslots), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const BnUpdateSlot*>(slots));
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 // ---------------------------------------------------------------------------
 // SyncBatchNorm exchange in fp32: every rank sends  mean[C] | M2[C] | count  (M2 = sum (x - mean)^2 over ITS samples; the
 // count travels as the bit pattern of an int32, gathers do no arithmetic) — 2C+1 words, all well scaled, unlike the raw

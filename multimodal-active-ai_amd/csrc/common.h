@@ -84,6 +84,11 @@ template <> struct Store<float> {
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
 };
 
+// a value as the storage type would hold it (bf16: one rounding; f32: unchanged)
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+
 // Non-temporal 16-byte accesses for tensors that are streamed once (activations of gigabytes, far beyond the 256 MB
 // Infinity Cache): measured on MI355X (scripts/probes/stream_probe.hip, 6.6 GB tensors) a 2-read-1-write stream moves
 // 5.3 TB/s with plain accesses and 6.0 TB/s non-temporal, a 1-read-1-write stream 5.4 -> 6.4 TB/s.

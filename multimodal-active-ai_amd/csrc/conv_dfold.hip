@@ -1,6 +1,6 @@
 // Data gradient of a FOLDED 64 -> 256 unit (conv3 + bn3 of layer 1's bottlenecks and layer1.0's projection shortcut,
 // resnet.py:118-123; engine._FOLD, csrc/fold.hip), bf16, one launch:
-//     dx = ( [g | a2] . Wcat^T + cn ) * [a2 > 0]          Wcat[k] = [ k1*W[:,k] | -(W^T diag(k3) W)[:,k] ]   (64 x 320)
+//     dx = ( [g | a2] . Wcat^T + cn + dg*a2 ) * [a2 > 0]  Wcat[k] = [ k1*W[:,k] | -(W^T diag(k3) W)[:,k], diagonal in dg ]   (64 x 320)
 // where g [M][256] is the gradient of bn3's OUTPUT as the block above left it (no BatchNorm-backward apply pass, no dz3
 // tensor, y3 not read), a2 = relu(bn2(y2)) is formed on load from the raw y2 [M][64], + the BatchNorm-backward partial sums
 // of the unit below (sum dx, sum dx*(y2 - mean2)) and optionally dx += (the shortcut branch accumulates onto the main one).
@@ -18,6 +18,7 @@ struct DfoldArgs {
   const void* y2;      // [M][64]
   const void* w;       // [64][320]: Wcat (maai_fold_dgrad_w with pitch 320)
   const float* cn;     // [64]
+  const float* dg;     // [64] fp32: the diagonal of -(W^T diag(k3) W), kept out of Wcat (nullable)
   const float* mean2;  // [64] bn2: mean | scale | shift
   const float* s2;
   const float* t2;
@@ -81,12 +82,13 @@ __global__ __launch_bounds__(256, 3) void conv_dfold_kernel(DfoldArgs a) {
       yv[i * NIT + it] = *reinterpret_cast<const uint4*>(y2p + m * KC2 + ec * 8);
       if constexpr (ACC) pv[i * NIT + it] = *reinterpret_cast<const uint4*>(dx + m * BN + ec * 8);
     }
-  float cnc[4], m2[8], sc2[8], sh2[8], s1[8], s2[8];
+  float cnc[4], m2[8], sc2[8], sh2[8], dgr[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) cnc[j] = a.cn[j * 16 + (lane & 15)];   // C layout: this lane's column of accumulator tile j
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     m2[e] = a.mean2[ec * 8 + e];
+    dgr[e] = a.dg ? a.dg[ec * 8 + e] : 0.f;
     sc2[e] = a.s2[ec * 8 + e];
     sh2[e] = a.t2[ec * 8 + e];
     s1[e] = 0.f;
@@ -193,6 +195,8 @@ __global__ __launch_bounds__(256, 3) void conv_dfold_kernel(DfoldArgs a) {
       float fv[8], fy[8];
       v.get(fv);
       vy.get(fy);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fv[e] += dgr[e] * fmaxf(round_as<T>(fy[e] * sc2[e] + sh2[e]), 0.f);   // T's diagonal, in fp32
       if constexpr (ACC) {
         Vec16<T> vp;
         vp.raw = pv[i * NIT + it];
@@ -244,12 +248,12 @@ extern "C" long long maai_conv_dfold_rows(long long M) { return (M + 127) / 128;
 
 // g [M][256], y2 [M][64] bf16; w = Wcat [64][320] bf16; cn, mean2, s2, t2 [64] fp32; dx [M][64] bf16 (accumulate != 0: += in
 // place, before the mask; the sums are those of the stored result); slab [maai_conv_dfold_rows(M)][2][64] fp32.
-extern "C" int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* mean2, const float* s2,
-                               const float* t2, void* dx, float* slab, long long M, int accumulate, void* stream) {
+extern "C" int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* dg, const float* mean2,
+                               const float* s2, const float* t2, void* dx, float* slab, long long M, int accumulate, void* stream) {
   MAAI_CHECK_ARG(g && y2 && w && cn && mean2 && s2 && t2 && dx && slab && M > 0, "conv_dfold: null pointer");
   MAAI_CHECK_ARG(M < (1ll << 31), "conv_dfold: pixel count must fit 31 bits");
   DfoldArgs a;
-  a.g = g; a.y2 = y2; a.w = w; a.cn = cn; a.mean2 = mean2; a.s2 = s2; a.t2 = t2; a.dx = dx; a.slab = slab; a.M = M;
+  a.g = g; a.y2 = y2; a.w = w; a.cn = cn; a.dg = dg; a.mean2 = mean2; a.s2 = s2; a.t2 = t2; a.dx = dx; a.slab = slab; a.M = M;
   a.nMB = (int)((M + 127) / 128);
   constexpr int lds = 5 * 64 * 64 + 4 * 16 * 72 * 2 + 8 * 64 * 4 + 2 * 64 * 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

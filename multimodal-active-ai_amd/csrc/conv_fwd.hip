@@ -318,6 +318,19 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
   a.pre_relu = epi ? epi->pre_relu : 0;
   a.pre_cin = epi ? epi->pre_cin : 0;
   a.pre_y_out = epi ? epi->pre_y_out : nullptr;
+  a.x2 = epi ? epi->x2 : nullptr;
+  a.cin1 = epi ? epi->cin1 : 0;
+  a.ebias = epi ? epi->bias : nullptr;
+  a.ediag = epi ? epi->diag : nullptr;
+  MAAI_CHECK_ARG(!a.ediag || (emode == MAAI_EPI_DGRAD_REDUCE && epi->t && epi->p1 && epi->p2),
+                 "conv2d_igemm: diag needs the DGRAD_REDUCE epilogue with the lower unit's raw output, scale and shift");
+  if (a.x2 || a.ebias) {
+    const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
+    MAAI_CHECK_ARG(emode == MAAI_EPI_DGRAD_REDUCE && dtype == MAAI_BF16 && pw1 && !a.xs && !a.a2 && !a.pre_x,
+                   "conv2d_igemm: the two-source input and the bias belong to bf16 pointwise DGRAD_REDUCE launches");
+    MAAI_CHECK_ARG(!a.x2 || (a.cin1 > 0 && a.cin1 < d->Cin && a.cin1 % 64 == 0 && (d->Cin - a.cin1) % 64 == 0),
+                   "conv2d_igemm: the two-source input splits Cin into two multiples of 64");
+  }
   const bool pws = pws_selected(d, epi, dtype);
   if (a.x_bits && !a.xb) {
     MAAI_CHECK_ARG(emode == MAAI_EPI_BN_ACT && pws && !a.xs && a.erelu && dtype == MAAI_BF16,

@@ -101,6 +101,13 @@ struct ConvArgs {
   const float* pre_xt;
   int pre_relu, pre_cin;
   void* pre_y_out;
+  // two-source A operand (pointwise EMODE 6 launches: the folded unit's data gradient, engine._FOLD): input channels
+  // [0, cin1) come from x (row pitch cin1), [cin1, Cin) from x2 (row pitch Cin - cin1); ebias (nullable, [Cout]) is added to
+  // the accumulators before they are rounded
+  const void* x2;
+  int cin1;
+  const float* ebias;
+  const float* ediag;   // EMODE 6 (with ep1/ep2/et): out += ediag[c] * relu(r(et*ep1 + ep2)) — the folded data gradient's fp32 diagonal
 };
 
 // EMODE: 0 plain store, 1 statistics only, 2..4 fused BN epilogues, 5 store with accumulate and/or ReLU mask,
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
   // ---- per-thread row decode (fixed for the whole K loop); 32-bit arithmetic (M < 2^31 is checked on the host),
   //      and no decode at all for pointwise stride-1 layers where the input pixel IS the output pixel ----
   long long abase[AR];
+  long long abase2[AR];   // two-source operand (pointwise EMODE 6): the row's offset in x2, minus cin1 (so that + kt*BK indexes it)
   int ihb[AR], iwb[AR];
   const unsigned ohw = (unsigned)(a.OHg * a.OWg);
   constexpr bool pointwise = PW;
@@ -169,7 +177,8 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
       if (pointwise) {
         ihb[i] = 0;
         iwb[i] = 0;
-        abase[i] = m * a.Cin + chunk * EPC;
+        abase[i] = m * (a.x2 ? a.cin1 : a.Cin) + chunk * EPC;
+        if constexpr (PW && EMODE == 6 && XF == 0) abase2[i] = m * (a.Cin - a.cin1) + chunk * EPC - a.cin1;
       } else {
         const unsigned mu = (unsigned)m;
         const unsigned n = mu / ohw;
@@ -223,10 +232,13 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
     const long long tapoff = PW ? (long long)kt * BK : ((long long)kh * a.IW + kw) * a.Cin + c0;
     char* sa = smem + slot * STAGE + widu * 1024;
     char* sb = sa + BM * 64;
+    // (two-source operand, pointwise EMODE 6 only: K-steps past cin1 read the second tensor, whose rows are Cin - cin1 long)
+    const bool second = PW && EMODE == 6 && XF == 0 && a.x2 != nullptr && kt * BK >= a.cin1;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = PW ? (ihb[i] >= 0) : ((unsigned)(ihb[i] + kh) < (unsigned)a.IH && (unsigned)(iwb[i] + kw) < (unsigned)a.IW);
       const T* src = ok ? (x + abase[i] + tapoff) : zsrc;
+      if (second && ok) src = reinterpret_cast<const T*>(a.x2) + abase2[i] + (long long)kt * BK;
       dma16<XF != 0>(src, sa + i * 4096);
     }
     if constexpr (XF == 2) {
@@ -571,12 +583,16 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
     // pair and four 16-bit LDS stores (low half / d16_hi) per 16x16 tile — no lane exchange, no selects, and
     // every address is one per-lane base plus a compile-time offset.
     unsigned short* cbase = reinterpret_cast<unsigned short*>(smem) + ((wm * WM) % CROWS + (lane >> 4) * 4) * LDC + wn * WN + (lane & 15);
+    float cbias[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cbias[j] = (EMODE == 6 && a.ebias) ? a.ebias[nb * BN + wn * WN + j * 16 + (lane & 15)] : 0.f;
     if (NPH == 1 || (wm * WM) / CROWS == ph) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const f32x4 v = acc[i][j];
+          f32x4 v = acc[i][j];
+          if constexpr (EMODE == 6) v += (f32x4){cbias[j], cbias[j], cbias[j], cbias[j]};
           const uint32_t p01 = pack_bf16x2(v[0], v[1]);
           const uint32_t p23 = pack_bf16x2(v[2], v[3]);
           // one v_cvt_pk per row PAIR: the low half goes out with ds_write_b16, the high half with its d16_hi form
@@ -709,7 +725,16 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 256) ? 2 : 3) void conv_ig
           for (int e = 0; e < NV; ++e) fv[e] += fo[e];
         }
         float fy[NV];
-        if constexpr (EMODE == 6) vy[b].get(fy);
+        if constexpr (EMODE == 6) {
+          vy[b].get(fy);
+          if (a.ediag) {   // (before the previous content and the mask: it is part of this launch's product)
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+              const float act = fmaxf(round_as<T>(fy[e] * q1[e] + q2[e]), 0.f);
+              fv[e] += a.ediag[cch0 + e] * act;
+            }
+          }
+        }
         if (a.mask) {
           if (EMODE == 6 && NV == 8 && a.mask_bits) {
 #pragma unroll

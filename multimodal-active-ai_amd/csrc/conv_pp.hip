@@ -76,7 +76,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
   const int prow = wid * 8 + (lane >> 3);            // quarter row of instruction 0 (instruction 1: + 64)
   const int lchunk = (lane & 7) ^ ((prow >> 1) & 7); // (+64 leaves (row >> 1) & 7 unchanged)
   int aoff[NAI][2];                                  // [i][mi]: element offset of the row's source at tap (0,0), channel lchunk*8
+  int aoff2[NAI][2];                                 // ... in the SECOND source tensor (two-source pointwise data gradients, a.x2)
   unsigned amask[NAI][2];                            // bit t: tap t reads inside the image (0: the row is past M)
+  const bool two = EMODE == 6 && a.x2 != nullptr;    // (host: pointwise, cin1 % 64 == 0)
+  const int pitch1 = two ? a.cin1 : a.Cin, pitch2 = a.Cin - a.cin1, nck1 = a.cin1 >> 6;
   const unsigned ohw = (unsigned)(a.OHg * a.OWg);
 #pragma unroll
   for (int i = 0; i < NAI; ++i) {
@@ -93,12 +96,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
         const unsigned rem = mu - n * ohw;
         const unsigned oh = rem / (unsigned)a.OWg, ow = rem - oh * (unsigned)a.OWg;
         const int ih0 = (int)oh * a.stride - a.pad_h, iw0 = (int)ow * a.stride - a.pad_w;
-        base = (int)((((long long)n * a.IH + ih0) * a.IW + iw0) * a.Cin) + lchunk * 8;   // (host: the input has < 2^31 elements)
+        base = (int)((((long long)n * a.IH + ih0) * a.IW + iw0) * pitch1) + lchunk * 8;   // (host: the input has < 2^31 elements)
         for (int kh = 0; kh < a.KH; ++kh)
           for (int kw = 0; kw < a.KW; ++kw)
             if ((unsigned)(ih0 + kh) < (unsigned)a.IH && (unsigned)(iw0 + kw) < (unsigned)a.IW) mask |= 1u << (kh * a.KW + kw);
       }
       aoff[i][mi] = base;
+      aoff2[i][mi] = two ? (int)(m < a.M ? m * pitch2 : 0) + lchunk * 8 : 0;
       amask[i][mi] = mask;
     }
   }
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
     for (int i = 0; i < NAI; ++i) {
       const bool ok = (amask[i][mi] >> it_tap) & 1u;
       const T* src = ok ? x + (long long)(aoff[i][mi] + it_off) : zsrc;
+      if (two && ok && it_ck >= nck1) src = reinterpret_cast<const T*>(a.x2) + (long long)(aoff2[i][mi] + (it_ck - nck1) * 64);
       dma16<true>(src, dst + i * 8192);
     }
   };
@@ -335,11 +340,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
   }
   {
     const uint32_t cwa = (uint32_t)(uintptr_t)(cw + ((fg * 4) * LDC + frow) * 2);
+    float cbias[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cbias[j] = (EMODE == 6 && a.ebias) ? a.ebias[col0 + j * 16 + frow] : 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const f32x4 v = acc[i][j];
+        f32x4 v = acc[i][j];
+        if constexpr (EMODE == 6) v += (f32x4){cbias[j], cbias[j], cbias[j], cbias[j]};
         const uint32_t p01 = pack_bf16x2(v[0], v[1]);
         const uint32_t p23 = pack_bf16x2(v[2], v[3]);
         asm volatile("ds_write_b16 %0, %1 offset:%2\n\tds_write_b16_d16_hi %0, %1 offset:%3" ::"v"(cwa), "v"(p01),
@@ -469,6 +478,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(ConvArgs a) {
           for (int e = 0; e < 8; ++e) fv[e] += fo[e];
         }
         vy[b].get(fy);
+        if (a.ediag) {   // the folded data gradient's fp32 diagonal: += diag[c] * relu(r(y*scale + shift)) (conv_igemm.h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] += a.ediag[col0 + cch * 8 + e] * fmaxf(round_as<T>(fy[e] * q1[e] + q2[e]), 0.f);
+        }
         if (a.mask) {
           if (a.mask_bits) {
 #pragma unroll
@@ -552,6 +565,7 @@ bool maai_conv_pp_supported(const ConvArgs& a, int dtype) {
   if (a.ostr != 1 || a.ooh != 0 || a.oow != 0 || a.OH != a.OHg || a.OW != a.OWg) return false;
   if ((long long)a.N * a.IH * a.IW * a.Cin >= (1ll << 31)) return false;
   if (a.xs || a.xb || a.a2 || a.pre_x) return false;
+  if (a.x2 && (a.emode != MAAI_EPI_DGRAD_REDUCE || a.KH * a.KW != 1 || a.stride != 1 || a.cin1 % 64 || (a.Cin - a.cin1) % 64)) return false;
   if (a.emode == MAAI_EPI_STORE) return !a.accumulate && !a.mask;
   if (a.emode == MAAI_EPI_BN_ACT) return a.Cout % 256 == 0 && !a.accumulate && !a.mask;   // (the 256 x 256 tile only)
   return a.emode == MAAI_EPI_DGRAD_REDUCE;

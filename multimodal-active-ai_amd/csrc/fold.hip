@@ -9,6 +9,7 @@
 //                    Tn[k][j] = bf16(-sum_c W[c,j] k3[c] W[c,k])    [Cin][Cin]: dx -= x (W^T diag(k3) W)
 //                    cn[k]    = -sum_c k2[c] W[c,k] - comp[k]       [Cin]:      dx -= k2 W; comp: the pixel mean of what rounding
 //                                                                   Wf and Tn to bf16 adds to dx[:, k] (fold_wf_kernel)
+//                    dg[k]    = -(W^T diag(k3) W)[k,k]              [Cin] fp32: T's diagonal, kept OUT of the bf16 matrix (fold_t_kernel)
 // W is the bf16 copy the forward MFMAs multiplied by (kernel layout [Cout][Cin]).  All of it is a few hundred MFLOP per unit:
 // plain fp32 loops, no tiling (measured: < 0.15 ms per unit at the largest shape, 2048 x 512).
 #include "common.h"
@@ -41,12 +42,14 @@ __global__ __launch_bounds__(256) void fold_dw_kernel(const bf16_t* __restrict__
 }
 
 // Tn[k][j] = bf16(-sum_c W[c][j] k3[c] W[c][k]): block = one k (row of Tn), threads stride over j; k3 * W[:, k] staged in LDS.
-// ct[k] = the mean, over the pixels the mask of output channel k KEEPS, of what rounding Tn to bf16 adds to dx[:, k] (see
-// fold_wf_kernel): sum_j dTn[k][j] * E[x_j | x_k > 0].  For j != k that conditional mean is taken as the plain mean sx[j] / N;
-// for j == k — the dominant entry: T's diagonal is a sum of squares — it is EXACT: x_k is zero wherever the mask drops the
-// pixel (the mask is x_k > 0, x post-ReLU), so sum_p mask*x_k = sx[k] over npos[k] kept pixels.
+// The DIAGONAL of T = W^T diag(k3) W is a sum of squares — sqrt(Cout) times larger than the off-diagonal entries — and the term
+// it multiplies, x[p][k], is what the mask of output channel k (x_k > 0) and the unit below's second BatchNorm-backward sum
+// (dx * (y2 - mean2), y2 -> x_k monotone) are built from: its bf16 rounding error would be the one coherent error of the folded
+// data gradient.  With ``dg`` it never enters the bf16 matrix: Tn[k][k] = 0 and dg[k] = -T[k][k] goes out in fp32 for the
+// epilogue of the data-gradient launch (dx[p][k] += dg[k] * x[p][k], x_k recomputed from the unit below's raw output).
+// ct[k] = sum_{j} sx[j] * (Tn[k][j] - exact) / N: the pixel mean of what rounding the REST of Tn adds to dx[:, k] (fold_wf_kernel).
 __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ w, const float* __restrict__ k3, const double* __restrict__ sx,
-                                                     const double* __restrict__ npos, double inv_n, bf16_t* __restrict__ tn, int tn_pitch,
+                                                     double inv_n, bf16_t* __restrict__ tn, int tn_pitch, float* __restrict__ dg,
                                                      float* __restrict__ ct, int Cout, int Cin) {
   extern __shared__ float wk[];   // k3[c] * W[c][k]
   __shared__ float red[256];
@@ -57,10 +60,14 @@ __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ 
   for (int j = threadIdx.x; j < Cin; j += 256) {
     float acc = 0.f;
     for (int c = 0; c < Cout; ++c) acc = fmaf(bf16_to_f32(w[(long long)c * Cin + j]), wk[c], acc);
+    if (dg && j == k) {
+      dg[k] = -acc;
+      tn[(long long)k * tn_pitch + j] = f32_to_bf16(0.f);
+      continue;
+    }
     const bf16_t r = f32_to_bf16(-acc);
     tn[(long long)k * tn_pitch + j] = r;
-    const double kept = (j == k && npos && npos[k] >= 1.0) ? 1.0 / npos[k] : inv_n;
-    bias = fmaf((float)(sx[j] * kept), bf16_to_f32(r) + acc, bias);
+    bias = fmaf((float)(sx[j] * inv_n), bf16_to_f32(r) + acc, bias);
   }
   red[threadIdx.x] = bias;
   __syncthreads();
@@ -74,9 +81,8 @@ __global__ __launch_bounds__(256) void fold_t_kernel(const bf16_t* __restrict__ 
 // Wf[k][c] = bf16(k1[c] W[c][k]); cn[k] = -sum_c k2[c] W[c][k] - (rounding compensation): block = one k, threads over c.
 // Rounding the folded weights to bf16 perturbs dx[p][k] by g[p] . dWf[k] + x[p] . dTn[k] — tiny per element, but COHERENT over
 // the pixels (the same weight error meets the non-zero means of g and of the post-ReLU x), which is exactly what the
-// BatchNorm-backward sums of the unit below add up.  Its mean over the pixels the mask keeps — s1 . dWf[k] / N (g taken as
-// independent of the mask) + fold_t_kernel's ct[k] — is known here and is taken out of the constant: the rounding error of the
-// folded weights is then zero-mean over the pixels that survive the mask (the constant only ever reaches those).
+// BatchNorm-backward sums of the unit below add up.  Its pixel mean — (s1 . dWf[k] + sx . dTn[k]) / N (fold_t_kernel's ct[k]) — is
+// known here and is taken out of the constant: the rounding error of the folded weights is then zero-mean over the pixels.
 __global__ __launch_bounds__(256) void fold_wf_kernel(const bf16_t* __restrict__ w, const float* __restrict__ k1, const float* __restrict__ k2,
                                                       const double* __restrict__ s1, const float* __restrict__ ct, double inv_n,
                                                       bf16_t* __restrict__ wf, int wf_pitch, float* __restrict__ cn, int Cout, int Cin) {
@@ -122,13 +128,14 @@ extern "C" int maai_fold_dw(const void* w, const float* g1, const float* gram, c
 }
 
 extern "C" int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const float* k3, const double* s1, const double* sx,
-                                 const double* npos, double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* scratch, int Cout, int Cin,
-                                 void* stream) {
+                                 double count, void* wf, int wf_pitch, void* tn, int tn_pitch, float* cn, float* dg, float* scratch, int Cout,
+                                 int Cin, void* stream) {
   MAAI_CHECK_ARG(w && k1 && k2 && k3 && s1 && sx && wf && tn && cn && scratch && count > 0 && Cout > 0 && Cin > 0 && Cout <= 8192 &&
                      wf_pitch >= Cout && tn_pitch >= Cin,
                  "fold_dgrad_w: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(fold_t_kernel, dim3(Cin), dim3(256), Cout * sizeof(float), st, (const bf16_t*)w, k3, sx, npos, 1.0 / count, (bf16_t*)tn, tn_pitch, scratch, Cout, Cin);
+  hipLaunchKernelGGL(fold_t_kernel, dim3(Cin), dim3(256), Cout * sizeof(float), st, (const bf16_t*)w, k3, sx, 1.0 / count, (bf16_t*)tn, tn_pitch,
+                     dg, scratch, Cout, Cin);
   hipLaunchKernelGGL(fold_wf_kernel, dim3(Cin), dim3(256), 0, st, (const bf16_t*)w, k1, k2, s1, scratch, 1.0 / count, (bf16_t*)wf, wf_pitch, cn, Cout, Cin);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

@@ -29,7 +29,8 @@ class ConvEpilogue(C.Structure):
     _fields_ = [("mode", c_i), ("relu", c_i), ("p0", c_p), ("p1", c_p), ("p2", c_p), ("t", c_p), ("mask_bits", c_i), ("sum_increment", c_i),
                 ("a2", c_p), ("ak1", c_p), ("ak2", c_p), ("ak3", c_p), ("a_out", c_p),
                 ("xs", c_p), ("xt", c_p), ("x_relu", c_i), ("xb", c_p), ("xs2", c_p), ("xt2", c_p), ("x_out", c_p), ("x_bits", c_p),
-                ("pre_x", c_p), ("pre_w", c_p), ("pre_xs", c_p), ("pre_xt", c_p), ("pre_relu", c_i), ("pre_cin", c_i), ("pre_y_out", c_p)]
+                ("pre_x", c_p), ("pre_w", c_p), ("pre_xs", c_p), ("pre_xt", c_p), ("pre_relu", c_i), ("pre_cin", c_i), ("pre_y_out", c_p),
+                ("x2", c_p), ("cin1", c_i), ("bias", c_p), ("diag", c_p)]
 
 
 EPI_STORE, EPI_STATS_ONLY, EPI_BN_ACT, EPI_BWD_REDUCE, EPI_BWD_APPLY, EPI_DGRAD_REDUCE = range(6)
@@ -58,6 +59,7 @@ SIGNATURES = {
     "maai_conv2d_wgrad_xf": (c_i, [_P_DESC, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_p]),
     "maai_reduce_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p]),
     "maai_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "maai_bn_running_update_multi": (c_i, [c_p, c_i, c_p]),
     "maai_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "maai_bn_act_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
     "maai_bn_act_fwd_mask": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_i, c_i, c_p]),
@@ -89,10 +91,10 @@ SIGNATURES = {
     "maai_sgd_step_multi": (c_i, [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_i, c_p]),
     "maai_fold_s2": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_fold_dw": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
-    "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
+    "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_gram": (c_i, [c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "maai_conv_dfold_rows": (c_ll, [c_ll]),
-    "maai_conv_dfold": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p]),
+    "maai_conv_dfold": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p]),
     "maai_comm_create": (c_i, [c_i, c_i, c_ll, c_p]),
     "maai_comm_handle": (c_i, [c_p, c_p]),
     "maai_comm_attach": (c_i, [c_p, c_i, c_p]),

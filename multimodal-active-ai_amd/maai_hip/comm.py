@@ -97,20 +97,23 @@ class P2PGather(object):
             self._h = C.c_void_p()
 
 
-_P2P = {"obj": None, "tried": False}
+_P2P = {}   # tag -> {"obj": P2PGather or None, "tried": bool}
 
 
-def p2p_gather_for(nbytes, group=None):
-    """The process-wide P2PGather if MAAI_P2P_GATHER=1 and its setup succeeded on every rank, else None.  The first call
-    is collective (setup + agreement); later calls return the cached decision."""
+def p2p_gather_for(nbytes, group=None, tag="embeddings"):
+    """The process-wide P2PGather of stream ``tag`` if MAAI_P2P_GATHER=1 and its setup succeeded on every rank, else None.
+    The first call per tag is collective (setup + agreement); later calls return the cached decision.  One communicator PER
+    STREAM of gathers ("embeddings": the prefetched gathers on the side stream; "syncbn": the statistics gathers on the compute
+    stream): a communicator's epochs must be executed in the order they were issued, which only one stream guarantees."""
     if os.environ.get("MAAI_P2P_GATHER", "0") != "1":
         return None
-    if not _P2P["tried"]:
-        _P2P["tried"] = True
+    st = _P2P.setdefault(tag, {"obj": None, "tried": False})
+    if not st["tried"]:
+        st["tried"] = True
         try:
-            _P2P["obj"] = P2PGather(max(int(nbytes), 1 << 20), group=group)   # (raises on every rank, or on none)
+            st["obj"] = P2PGather(max(int(nbytes), 1 << 20), group=group)   # (raises on every rank, or on none)
         except MaaiError as e:
             import warnings
-            warnings.warn("MAAI_P2P_GATHER=1 but the symmetric buffers could not be set up (%s): using the RCCL all-gather" % e)
-    o = _P2P["obj"]
+            warnings.warn("MAAI_P2P_GATHER=1 but the symmetric buffers (%s) could not be set up (%s): using the RCCL all-gather" % (tag, e))
+    o = st["obj"]
     return o if (o is not None and nbytes <= o.max_bytes) else None

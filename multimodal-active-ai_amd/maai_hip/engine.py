@@ -430,7 +430,19 @@ def _exchange(kind, vecs):
         world = dist.get_world_size()
         n = flat.numel()
         buf = torch.empty(world * n, dtype=flat.dtype, device=flat.device)   # (flat: what every backend's gather accepts)
-        dist.all_gather_into_tensor(buf, flat.contiguous())
+        p2p = None
+        if flat.is_cuda and os.environ.get("MAAI_P2P_GATHER", "0") == "1":
+            # the 98 forward gathers of a step are latency-bound messages of <= 16 KB on the compute stream: with
+            # MAAI_P2P_GATHER=1 they take the one-kernel direct all-gather of csrc/comm.hip (adopted by all ranks or none;
+            # consecutive gathers synchronise themselves: nobody finishes epoch e before everybody has written it, so no rank
+            # runs more than one gather ahead — the two epoch parities suffice)
+            from . import comm
+            p2p = comm.p2p_gather_for(4 * n, tag="syncbn")
+        if p2p is not None:
+            p2p.gather(flat.contiguous().view(1, n), buf.view(world, n))
+            EXCHANGES["p2p"] = EXCHANGES.get("p2p", 0) + 1
+        else:
+            dist.all_gather_into_tensor(buf, flat.contiguous())
         out = buf.view(world, n)
         res, o = [], 0
         for v in vecs:
@@ -454,10 +466,125 @@ _NBT = {"depth": 0, "pending": []}
 
 
 def _count_batch(bn):
-    if _NBT["depth"] > 0:
+    if _DEFER["stats"] is not None:
+        _DEFER["nbt"].append(bn.num_batches_tracked)    # (applied with the running statistics, after the streams have joined)
+    elif _NBT["depth"] > 0:
         _NBT["pending"].append(bn.num_batches_tracked)
     else:
         bn.num_batches_tracked += 1
+
+
+# The two forwards of a SimCLR step on two HIP streams (MAAI_OVERLAP_VIEWS=1 / set_overlap_views): the
+# no-grad view-1 forward (Contrastive_Learning.py:638-640 under torch.no_grad, as bench.py runs it) is enqueued on a side
+# stream and the gradient-carrying view-2 forward on the caller's stream right behind it; the device then has launches of
+# both to overlap (an HBM-bound launch of one next to an MFMA-bound one of the other, tails next to heads).  The two are
+# independent but for the BatchNorm buffers: while a forward is in flight on the side stream, every training-mode BatchNorm
+# of EITHER forward writes its (float)mean / (float)unbiased variance to scratch instead of touching running_mean / running_var
+# / num_batches_tracked, and when the second forward has been enqueued the caller's stream waits for the side stream and ONE
+# launch applies both updates of every layer in program order (kernels.bn_running_update_multi): the buffers are bit-identical
+# to two forwards run one after the other.  The output of the side forward is valid on the caller's stream after that join —
+# which also happens at the next loss / optimiser / forward call, whichever comes first (``flush_overlap``).
+# Single rank only (SyncBatchNorm's collectives stay on one stream), training mode, no block recompute.
+_OVL = {"enabled": os.environ.get("MAAI_OVERLAP_VIEWS", "0") == "1", "stream": None, "pending": None}
+_DEFER = {"stats": None, "nbt": None, "buf": None, "bufs": None}
+
+
+def set_overlap_views(flag):
+    flush_overlap()
+    _OVL["enabled"] = bool(flag)
+
+
+class _Pending(object):
+    __slots__ = ("stream", "stats", "nbt", "out", "bufs")
+
+
+def _defer_stats(bn, c, device):
+    """Scratch for one BatchNorm's deferred statistics: (mean, unbiased variance) fp32 [C] each, zeroed — slices of ONE flat
+    buffer per forward (``_DEFER["buf"]``: [tensor, offset], grown in 64 K-float steps); recorded for the join."""
+    buf = _DEFER["buf"]
+    if buf[0] is None or buf[1] + 2 * c > buf[0].numel():
+        buf[0], buf[1] = torch.zeros(max(65536, 2 * c), dtype=torch.float32, device=device), 0
+        _DEFER["bufs"].append(buf[0])
+    m, v = buf[0][buf[1]:buf[1] + c], buf[0][buf[1] + c:buf[1] + 2 * c]
+    buf[1] += 2 * c
+    _DEFER["stats"].append((bn, m, v))
+    return m, v
+
+
+def _defer_begin(stats, nbt):
+    _DEFER["stats"], _DEFER["nbt"], _DEFER["buf"], _DEFER["bufs"] = stats, nbt, [None, 0], []
+
+
+def _defer_end():
+    bufs = _DEFER["bufs"]
+    _DEFER["stats"] = _DEFER["nbt"] = _DEFER["buf"] = _DEFER["bufs"] = None
+    return bufs
+
+
+def flush_overlap():
+    """Join a forward that is in flight on the side stream (if any) and apply the deferred BatchNorm buffer updates."""
+    pend = _OVL["pending"]
+    if pend is None:
+        return
+    _OVL["pending"] = None
+    _join_overlap(pend, None, None)
+
+
+def _join_overlap(pend, stats2, nbt2):
+    cur = torch.cuda.current_stream()
+    cur.wait_stream(pend.stream)
+    for t in ([pend.out] if pend.out is not None else []) + list(pend.bufs or []):
+        t.record_stream(cur)   # (allocated on the side stream, read on this one from here on)
+    order, by = [], {}
+    for lst in (pend.stats, stats2 or []):
+        for (bn, m, v) in lst:
+            e = by.get(id(bn))
+            if e is None:
+                e = by[id(bn)] = [bn, [], []]
+                order.append(e)
+            e[1].append(m)
+            e[2].append(v)
+    items = []
+    for bn, ms, vs in order:
+        if len(ms) > 2:
+            raise MaaiError("overlapped forwards: a BatchNorm layer ran more than twice between two joins")
+        mom = bn.momentum
+        items.append((bn.running_mean, ms[0], ms[1] if len(ms) > 1 else None, mom))
+        items.append((bn.running_var, vs[0], vs[1] if len(vs) > 1 else None, mom))
+    K.bn_running_update_multi(items)
+    counts = {}
+    for t in list(pend.nbt) + list(nbt2 or []):
+        e = counts.setdefault(id(t), [t, 0])
+        e[1] += 1
+    for k in (1, 2):
+        ts = [t for t, n in counts.values() if n == k]
+        if ts:
+            torch._foreach_add_(ts, k)
+    if any(n > 2 for _, n in counts.values()):
+        raise MaaiError("overlapped forwards: a BatchNorm counter was incremented more than twice between two joins")
+
+
+def prewarm_weights(f, g, dtype, pool=None):
+    """Every kernel-layout weight copy a forward of (f, g) reads, (re)built NOW on the current stream — before two forwards
+    that both read them are enqueued on two streams."""
+    for m in f.modules():
+        if isinstance(m, torch.nn.Conv2d) and m is not f.conv1:
+            w_fwd(m.weight, dtype)
+    c1 = f.conv1
+    cin = c1.weight.shape[1]
+    if cin == 3 and c1.kernel_size == (7, 7) and c1.stride == (1, 1) and c1.padding == (3, 3):
+        w_stem_unrolled(c1.weight, dtype)
+    else:
+        w_fwd(c1.weight, dtype, (cin + 31) // 32 * 32)
+    if g is not None and hasattr(g, "layers"):
+        l0, l2 = g.layers[0], g.layers[2]
+        last = [m for m in f.modules() if isinstance(m, torch.nn.Conv2d)][-1]
+        c = None
+        for blk in _blocks(f):
+            c = (blk.conv3 if _is_bottleneck(blk) else blk.conv2).out_channels
+        if c and l0.in_features % c == 0:
+            w_linear(l0.weight, dtype, (c, l0.in_features // c))
+        w_linear(l2.weight, torch.float32)
 
 
 class _batched_counters(object):
@@ -659,6 +786,15 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         else:
             rm = rv = None
             mom = 0.0
+        if _DEFER["stats"] is not None and rm is not None:
+            if gathered is not None:
+                raise MaaiError("overlapped forwards are single-rank (SyncBatchNorm exchanges stay on one stream)")
+            # another forward is in flight: the statistics go to scratch (momentum 1 on zeroed buffers stores exactly
+            # (float)mean / (float)unbiased variance), the buffers are updated after the join
+            if bn.momentum is None:
+                raise MaaiError("overlapped forwards need a fixed BatchNorm momentum")
+            rm, rv = _defer_stats(bn, rm.numel(), rm.device)
+            mom = 1.0
         if gathered is not None:
             # (count: the MERGED sample count as a device scalar — the ranks' batches may differ, e.g. a last batch without
             #  drop_last — which the backward's 1/N takes as is: torch.nn.SyncBatchNorm uses the summed counts in both passes)
@@ -771,7 +907,7 @@ def axf_applies(rec, dz, below, need_dx=True):
 
 
 def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=False, relu_mask=None, below=None, axf=None,
-               sum_increment=False, wq_dgrad=None):
+               sum_increment=False, wq_dgrad=None, x2=None, bias=None, diag=None):
     """dx [N,IH,IW,Cin] of y = conv(x, weight[Cout,Cin,k,k]) from dy [N,OH,OW,Cout]; with ``relu_mask`` (= x,
     a post-ReLU tensor) the result is also multiplied by (x > 0) in the conv epilogue.  ``below`` = the record of
     the unit whose output x is: the mask is then that unit's, and where every pixel of dx is written exactly once
@@ -821,11 +957,15 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
     if axf is not None and not (fuse and len(launches) == 1):
         raise MaaiError("conv_dgrad: the transformed operand needs a single fused pointwise launch")
     if not fuse:
+        if x2 is not None or bias is not None or diag is not None:
+            raise MaaiError("conv_dgrad: the two-source input rides the fused (DGRAD_REDUCE) launch only")
         for (wq, pad_h, pad_w, grid, off) in launches:
             K.conv2d(dy, wq, 1, pad_h, pad_w, out=out, grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off,
                      accumulate=accumulate, relu_mask=relu_mask)
         return out, None
-    rows = [K.conv2d_stats_rows(dy, wq, 1, pad_h, pad_w, grid, (ih, iw), stride, off, axf=axf is not None)
+    if diag is not None and not from_y:
+        raise MaaiError("conv_dgrad: the fp32 diagonal needs the unit below's activation recomputed from its raw output (a plain conv-bn-relu unit)")
+    rows = [K.conv2d_stats_rows(dy, wq, 1, pad_h, pad_w, grid, (ih, iw), stride, off, axf=axf is not None, x2=x2)
             for (wq, pad_h, pad_w, grid, off) in launches]
     slab = torch.empty((sum(rows), 2, cin), dtype=torch.float32, device=dy.device)
     r0 = 0
@@ -833,7 +973,7 @@ def conv_dgrad(dy, weight, k, stride, pad, in_hw, dtype, out=None, accumulate=Fa
         K.conv2d_store_reduce(dy, wq, 1, pad_h, pad_w, out, slab[r0:r0 + nr], None if sum_only else below.y, _reduce_mean(below),
                               below.scale if from_y else None, below.shift if from_y else None, relu_mask,
                               grid_hw=grid, out_hw=(ih, iw), out_stride=stride, out_off=off, accumulate=accumulate,
-                              mask_bits=use_bits, axf=axf, sum_increment=incr)
+                              mask_bits=use_bits, axf=axf, sum_increment=incr, x2=x2, bias=bias, diag=diag)
         r0 += nr
     return out, K.reduce_partials(slab)
 
@@ -864,7 +1004,9 @@ def _grad_to_reference(rec, dw):
 # weights k1*W and W^T diag(k3) W are rounded to bf16 once each.  Pinned against the fp64 oracle per block
 # (tests/test_gpu_fold.py) — not bit-identical to the unfolded path.  MAAI_FOLD=0 turns it off.
 # MAAI_FOLD_FWD=0: the folded units' FORWARD stays a stored-output launch (only the backward changes).
-_FOLD = {"enabled": os.environ.get("MAAI_FOLD", "1") != "0", "fwd": os.environ.get("MAAI_FOLD_FWD", "1") != "0"}
+# MAAI_FOLD_CAT=0: the folded data gradient as two launches (x T first, then g (k1 W) accumulating) instead of one two-source launch.
+_FOLD = {"enabled": os.environ.get("MAAI_FOLD", "1") != "0", "fwd": os.environ.get("MAAI_FOLD_FWD", "1") != "0",
+         "cat": os.environ.get("MAAI_FOLD_CAT", "1") != "0"}
 
 
 def set_fold(flag, fwd=None):
@@ -1062,9 +1204,8 @@ def _unit_bwd_folded(rec, g, grads, dtype, k1, k2, k3, need_dx, dx_out, accumula
     cout, cin = w.shape[0], w.shape[1]
     wq = w_fwd(w, dtype).reshape(cout, cin)
     x = rec.x
-    npos = None
     if cin in K.GRAM_CHANNELS:
-        gram, sx, npos = K.gram(x)             # Gram = x^T x, colsum(x) and the count of x > 0 in one pass over x (csrc/gram.hip)
+        gram, sx = K.gram(x)                   # Gram = x^T x and colsum(x) in one pass over x (csrc/gram.hip)
     else:
         xm = materialise(x)
         sx = K.bn_act_bwd_reduce(xm, None, None, None, False)
@@ -1081,11 +1222,19 @@ def _unit_bwd_folded(rec, g, grads, dtype, k1, k2, k3, need_dx, dx_out, accumula
             and not below.fused and x.relu and relu_mask is None and _DGRAD_REDUCE["enabled"] and (dx_out is None) == (not accumulate)):
         # layer 1: [g | a2] against the concatenated folded weights in ONE launch, a2 formed on load from the unit below's raw
         # output, that unit's mask and BatchNorm-backward sums in the epilogue (csrc/conv_dfold.hip)
-        wcat, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, cat=True, npos=npos)
-        dx, slab = K.conv_dfold(g, x.y, wcat, cn, _reduce_mean(below), below.scale, below.shift, dx=dx_out if accumulate else None)
+        wcat, cn, dg = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, cat=True)
+        dx, slab = K.conv_dfold(g, x.y, wcat, cn, _reduce_mean(below), below.scale, below.shift, dx=dx_out if accumulate else None, dg=dg)
         return dx, K.reduce_partials(slab)
     x = materialise(x)
-    wf, tn, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, npos=npos)
+    if (_FOLD["cat"] and below is not None and _DGRAD_REDUCE["enabled"] and below.y is not None and below.relu and not below.has_res
+            and not below.fused and below.scale is not None and relu_mask is None and cin % 64 == 0 and cout % 64 == 0):
+        # ONE launch: [g | x] against the concatenated folded weights (two-source operand of the ring / ping-pong kernels), the
+        # constant added before rounding, T's diagonal in fp32 on the unit below's activation recomputed in the epilogue, that
+        # unit's mask and BatchNorm-backward sums
+        wcat, cn, dg = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix, cat=True)
+        return conv_dgrad(g, w, 1, 1, 0, rec.in_hw, dtype, out=dx_out, accumulate=accumulate, relu_mask=None, below=below,
+                          sum_increment=False, wq_dgrad=wcat, x2=x, bias=cn, diag=dg)
+    wf, tn, cn = K.fold_dgrad_weights(wq, k1, k2, k3, f.s1, sx, npix)
     # dx = g (k1 W) - x (W^T diag(k3) W) - k2 W: the short term first (K = Cin, a pointwise launch whose epilogue adds the
     # constant and — shortcut units — what is already in dx), then the long one accumulates onto it with the mask and the
     # BatchNorm-backward sums of the unit below in its epilogue
@@ -1592,6 +1741,7 @@ class _BlockFn(torch.autograd.Function):
 
 def block_forward(blk, x):
     """``blk(x)`` for one BasicBlock / Bottleneck of this package's ResNet on the HIP engine."""
+    flush_overlap()
     _need_gpu_module(blk)
     if not x.is_cuda:
         raise MaaiError("the HIP path needs tensors on a HIP device (got %s); there is no CPU fallback" % x.device)
@@ -1625,14 +1775,55 @@ class _HeadFn(torch.autograd.Function):
         return (dv, None, None) + tuple(grads.get(id(p)) for p in ctx.params)
 
 
+def _overlap_ok(f, x, keep):
+    if not (_OVL["enabled"] and not keep and f.training and not _RECOMPUTE["enabled"]):
+        return False
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False
+    xs = x if isinstance(x, (list, tuple)) else [x]
+    return all(torch.is_tensor(t) and t.is_cuda for t in xs)
+
+
 def fused_forward(f, g, x, pool=None):
     _need_gpu_module(f)
     params = trainable_params(f, g)
     keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-    return _FusedFn.apply(x, f, g, pool, keep, *params)
+    pend = _OVL["pending"]
+    if pend is None and _overlap_ok(f, x, keep):
+        # the no-grad view: enqueued on the side stream; the next forward (or loss / optimiser call) joins it
+        if _OVL["stream"] is None:
+            _OVL["stream"] = torch.cuda.Stream()
+        side, cur = _OVL["stream"], torch.cuda.current_stream()
+        prewarm_weights(f, g, compute_dtype(), pool)
+        side.wait_stream(cur)
+        pend = _Pending()
+        pend.stream, pend.stats, pend.nbt, pend.out, pend.bufs = side, [], [], None, None
+        _defer_begin(pend.stats, pend.nbt)
+        try:
+            with torch.cuda.stream(side):
+                pend.out = _FusedFn.apply(x, f, g, pool, False, *params)
+        finally:
+            pend.bufs = _defer_end()
+        for t in (x if isinstance(x, (list, tuple)) else [x]):
+            t.record_stream(side)
+        _OVL["pending"] = pend
+        return pend.out
+    if pend is None:
+        return _FusedFn.apply(x, f, g, pool, keep, *params)
+    # a forward is in flight on the side stream: this one defers its BatchNorm buffer updates too, then joins
+    _OVL["pending"] = None
+    stats2, nbt2 = [], []
+    _defer_begin(stats2, nbt2)
+    try:
+        z = _FusedFn.apply(x, f, g, pool, keep, *params)
+    finally:
+        _defer_end()
+        _join_overlap(pend, stats2, nbt2)
+    return z
 
 
 def backbone_forward(f, x):
+    flush_overlap()
     _need_gpu_module(f)
     params = trainable_params(f)
     keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
@@ -1640,6 +1831,7 @@ def backbone_forward(f, x):
 
 
 def head_forward(g, v):
+    flush_overlap()
     _need_gpu_module(g)
     params = trainable_params(g)
     keep = torch.is_grad_enabled() and (v.requires_grad or any(p.requires_grad for p in params))

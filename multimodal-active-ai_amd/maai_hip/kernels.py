@@ -118,8 +118,12 @@ def conv_out_hw(ih, iw, kh, kw, stride, pad_h, pad_w):
     return (ih + 2 * pad_h - kh) // stride + 1, (iw + 2 * pad_w - kw) // stride + 1
 
 
-def make_desc(x, w, stride, pad_h, pad_w, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False):
+def make_desc(x, w, stride, pad_h, pad_w, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, x2=None):
     n, ih, iw, cin = x.shape
+    if x2 is not None:   # two-source input: the channels of x followed by those of x2
+        if tuple(x2.shape[:3]) != (n, ih, iw) or x2.dtype != x.dtype:
+            raise MaaiError("conv2d: the second input tensor must cover the same pixels in the same dtype")
+        cin += x2.shape[3]
     cout, kh, kw, cin_w = w.shape
     if cin != cin_w:
         raise MaaiError("conv2d: Cin mismatch %d vs %d" % (cin, cin_w))
@@ -289,9 +293,9 @@ def _conv2d_lazy(xf, w, stride, pad_h, pad_w, stats, join_out, join_bits):
     return ret if len(ret) > 1 else ret[0]
 
 
-def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), axf=False):
+def conv2d_stats_rows(x, w, stride=1, pad_h=0, pad_w=0, grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), axf=False, x2=None):
     """Rows of the partial-sum slab one conv2d launch of this geometry writes (``axf``: transformed-operand launch)."""
-    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, False)
+    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, False, x2=x2)
     if axf:
         return (d.N * d.OHg * d.OWg + 127) // 128
     return int(lib().maai_conv2d_stats_rows(C.byref(d), _dt(x)))
@@ -316,13 +320,15 @@ def conv2d_kernel_family(x, w, stride=1, pad_h=0, pad_w=0):
 
 def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, scale=None, shift=None, relu_mask=None,
                         grid_hw=None, out_hw=None, out_stride=1, out_off=(0, 0), accumulate=False, mask_bits=False, axf=None,
-                        sum_increment=False):
+                        sum_increment=False, x2=None, bias=None, diag=None):
     """conv2d(..., out=out) for a data gradient whose epilogue also reduces the BatchNorm-backward partial sums of
     the stored values g: rows of ``part`` [rows,2,Cout] get sum(g) and sum(g*(lower_y - mean)).  The ReLU mask is
     ``relu_mask > 0`` or, without it, ``lower_y*scale + shift > 0`` (MAAI_EPI_DGRAD_REDUCE).
     ``axf = (y_raw, k1, k2, k3, dy_out)``: x is dz and the GEMM operand is k1*dz - k2 - k3*y_raw (BatchNorm-backward
-    apply of the layer above), formed while staging; dy_out (or None) receives it.  Pointwise bf16 layers only."""
-    _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask)
+    apply of the layer above), formed while staging; dy_out (or None) receives it.  Pointwise bf16 layers only.
+    ``x2`` / ``bias``: the input is the channel concatenation [x | x2] of two tensors (w: [Cout,1,1,Cx+Cx2]) and ``bias`` [Cout]
+    is added before rounding — the data gradient of a unit whose BatchNorm backward is folded (``fold_dgrad_weights(cat=True)``)."""
+    _gpu(x, w, out, part, lower_y, mean, scale, shift, relu_mask, x2, bias, diag)
     if x.dtype != w.dtype or (lower_y is not None and (lower_y.dtype != out.dtype or lower_y.shape != out.shape)):
         raise MaaiError("conv2d_store_reduce: operand dtype / shape mismatch")
     if lower_y is None and relu_mask is None:
@@ -333,7 +339,7 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
             raise MaaiError("conv2d_store_reduce: the 1-bit mask must be uint8 [numel/8] over a bf16 output")
     elif relu_mask is not None and (relu_mask.shape != out.shape or relu_mask.dtype != out.dtype):
         raise MaaiError("conv2d_store_reduce: relu_mask must have the output's shape and dtype")
-    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate)
+    d = make_desc(x, w, stride, pad_h, pad_w, grid_hw, out_hw, out_stride, out_off, accumulate, x2=x2)
     epi = ConvEpilogue(EPI_DGRAD_REDUCE, 0, mean.data_ptr(), None if scale is None else scale.data_ptr(),
                        None if shift is None else shift.data_ptr(), None if lower_y is None else lower_y.data_ptr(), 1 if mask_bits else 0,
                        1 if (sum_increment and accumulate) else 0)
@@ -344,6 +350,16 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
             raise MaaiError("conv2d_store_reduce: the transformed operand's tensors must match x")
         epi.a2, epi.ak1, epi.ak2, epi.ak3 = ya.data_ptr(), k1.data_ptr(), k2.data_ptr(), k3.data_ptr()
         epi.a_out = None if dyo is None else dyo.data_ptr()
+    if x2 is not None:
+        epi.x2, epi.cin1 = x2.data_ptr(), x.shape[-1]
+    if bias is not None:
+        if bias.dtype != torch.float32 or bias.numel() != d.Cout:
+            raise MaaiError("conv2d_store_reduce: bias is fp32 [Cout]")
+        epi.bias = bias.data_ptr()
+    if diag is not None:
+        if lower_y is None or scale is None or shift is None or diag.dtype != torch.float32 or diag.numel() != d.Cout:
+            raise MaaiError("conv2d_store_reduce: diag is fp32 [Cout] and needs the lower unit's raw output, scale and shift")
+        epi.diag = diag.data_ptr()
     rows = int(lib().maai_conv2d_stats_rows_fused(C.byref(d), C.byref(epi), _dt(x)))
     if part.dtype != torch.float32 or not part.is_contiguous() or tuple(part.shape) != (rows, 2, d.Cout):
         raise MaaiError("conv2d_store_reduce: partial slab must be fp32 [%d, 2, %d]" % (rows, d.Cout))
@@ -351,7 +367,7 @@ def conv2d_store_reduce(x, w, stride, pad_h, pad_w, out, part, lower_y, mean, sc
     es = x.element_size()
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[red] M%d Cin%d Cout%d k%dx%d s%d os%d acc%d" % (m, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_stride, d.accumulate)
     with _timed(nm, 2.0 * m * d.Cout * d.KH * d.KW * d.Cin * FLOPS_SCALE[0],
-                es * (x.numel() * (1 if axf is None else (3 if axf[4] is not None else 2)) + w.numel()
+                es * (x.numel() * (1 if axf is None else (3 if axf[4] is not None else 2)) + (0 if x2 is None else x2.numel()) + w.numel()
                       + m * d.Cout * ((1 if lower_y is None else 2) + (1 if accumulate else 0) + (0 if (relu_mask is None or mask_bits) else 1)))
                 + (m * d.Cout // 8 if mask_bits else 0), es * (x.numel() + m * d.Cout)):
         check(lib().maai_conv2d_igemm_fused(C.byref(d), _p(x), _p(w), _p(out), _p(part), _p(relu_mask), C.byref(epi), _dt(x), _stream()),
@@ -639,6 +655,31 @@ def bn_finalize_gathered(gathered, gamma, beta, running_mean, running_var, momen
     return mean, invstd, scale, shift, count
 
 
+BN_UPDATE_SLOT = [("running", "<u8"), ("stat_a", "<u8"), ("stat_b", "<u8"), ("n", "<i8"), ("momentum", "<f4"), ("reserved", "<i4")]   # maai_bn_update_slot
+
+
+def bn_running_update_multi(items):
+    """``items``: [(running tensor, stat_a, stat_b or None, momentum)]: running <- (1-m)*running + m*stat_a, then stat_b, for
+    every entry in ONE launch (maai_bn_running_update_multi; every running tensor at most once)."""
+    import numpy as np
+    if not items:
+        return
+    tab = np.zeros(len(items), dtype=BN_UPDATE_SLOT)
+    seen = set()
+    for i, (r, a, b, mom) in enumerate(items):
+        _gpu(r, a, b)
+        if r.dtype != torch.float32 or a.dtype != torch.float32 or a.numel() != r.numel() or (b is not None and (b.dtype != torch.float32 or b.numel() != r.numel())):
+            raise MaaiError("bn_running_update_multi: fp32 tensors of one size per entry")
+        if r.data_ptr() in seen:
+            raise MaaiError("bn_running_update_multi: a running buffer may appear once (two updates go into one entry)")
+        seen.add(r.data_ptr())
+        tab[i] = (r.data_ptr(), a.data_ptr(), 0 if b is None else b.data_ptr(), r.numel(), float(mom), 0)
+    dev = items[0][0].device
+    tdev = torch.from_numpy(tab.view(np.uint8)).to(dev)
+    check(lib().maai_bn_running_update_multi(_p(tdev), len(items), _stream()), "maai_bn_running_update_multi")
+    tdev.record_stream(torch.cuda.current_stream())
+
+
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     _gpu(running_mean, running_var)
     c = running_mean.numel()
@@ -769,28 +810,29 @@ def fold_dw(wq, g1, gram, sx, k1, k2, k3):
     return dw
 
 
-def fold_dgrad_weights(wq, k1, k2, k3, s1, sx, count, cat=False, npos=None):
-    """(wf [Cin,1,1,Cout] bf16 = k1*W in data-gradient form, tn [Cin,1,1,Cin] bf16 = -(W^T diag(k3) W), cn [Cin] fp32 = -(k2 W)
-    minus the pixel mean of what rounding wf and tn adds to dx: ``s1`` = sum g [Cout], ``sx`` = colsum x [Cin] (fp64) over
-    ``count`` pixels; ``npos`` [Cin] fp64 = pixels with x_k > 0, from ``gram``: the diagonal of tn is compensated exactly).
-    ``cat``: ONE matrix Wcat [Cin,1,1,Cout+Cin] = [wf | tn] (what ``conv_dfold`` multiplies by) -> (wcat, cn)."""
-    _gpu(wq, k1, k2, k3, s1, sx, npos)
+def fold_dgrad_weights(wq, k1, k2, k3, s1, sx, count, cat=False):
+    """The folded data gradient's weights.  ``cat`` False: (wf [Cin,1,1,Cout] bf16 = k1*W in data-gradient form, tn [Cin,1,1,Cin]
+    bf16 = -(W^T diag(k3) W), cn [Cin] fp32 = -(k2 W) minus the pixel mean of what rounding wf and tn adds to dx: ``s1`` = sum g
+    [Cout], ``sx`` = colsum x [Cin] (fp64) over ``count`` pixels).  ``cat``: ONE matrix Wcat [Cin,1,1,Cout+Cin] = [wf | tn] with
+    tn's DIAGONAL zeroed and returned in fp32 — (wcat, cn, dg): the two-source launch / ``conv_dfold`` add dg[k]*x[p][k] in
+    their epilogue (that entry is the large one of its row and meets the mask's own channel: it is kept out of bf16)."""
+    _gpu(wq, k1, k2, k3, s1, sx)
     cout, cin = wq.shape[0], wq.numel() // wq.shape[0]
-    if s1.dtype != torch.float64 or sx.dtype != torch.float64 or s1.numel() < cout or sx.numel() < cin or \
-            (npos is not None and (npos.dtype != torch.float64 or npos.numel() < cin)):
+    if s1.dtype != torch.float64 or sx.dtype != torch.float64 or s1.numel() < cout or sx.numel() < cin:
         raise MaaiError("fold_dgrad_weights: fp64 s1 [Cout], sx [Cin]")
     cn = torch.empty(cin, dtype=torch.float32, device=wq.device)
     scratch = torch.empty(cin, dtype=torch.float32, device=wq.device)
     if cat:
         wcat = torch.empty((cin, 1, 1, cout + cin), dtype=torch.bfloat16, device=wq.device)
+        dg = torch.empty(cin, dtype=torch.float32, device=wq.device)
         tnp = C.c_void_p(wcat.data_ptr() + 2 * cout)
-        check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), _p(npos), float(count), _p(wcat), cout + cin, tnp, cout + cin,
-                                      _p(cn), _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
-        return wcat, cn
+        check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), float(count), _p(wcat), cout + cin, tnp, cout + cin,
+                                      _p(cn), _p(dg), _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
+        return wcat, cn, dg
     wf = torch.empty((cin, 1, 1, cout), dtype=torch.bfloat16, device=wq.device)
     tn = torch.empty((cin, 1, 1, cin), dtype=torch.bfloat16, device=wq.device)
-    check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), _p(npos), float(count), _p(wf), cout, _p(tn), cin, _p(cn),
-                                  _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
+    check(lib().maai_fold_dgrad_w(_p(wq), _p(k1), _p(k2), _p(k3), _p(s1), _p(sx), float(count), _p(wf), cout, _p(tn), cin, _p(cn),
+                                  None, _p(scratch), cout, cin, _stream()), "maai_fold_dgrad_w")
     return wf, tn, cn
 
 
@@ -798,7 +840,7 @@ GRAM_CHANNELS = (64, 128, 256, 512)
 
 
 def gram(x):
-    """(Gram = x^T x [C,C] fp32, sx = colsum(x) [C] fp64, npos [C] fp64 = rows with x > 0) of an activation [.., C] bf16 — a tensor or a single-tensor ``Lazy``
+    """(Gram = x^T x [C,C] fp32, sx = colsum(x) [C] fp64) of an activation [.., C] bf16 — a tensor or a single-tensor ``Lazy``
     (formed on load).  csrc/gram.hip; accumulated with atomics: last-bit run-to-run differences, like every weight gradient."""
     xs = xt = None
     x_relu = 0
@@ -813,17 +855,16 @@ def gram(x):
         raise MaaiError("gram: bf16 activations with 64, 128, 256 or 512 channels")
     m = x.numel() // c
     g = torch.zeros((c, c), dtype=torch.float32, device=x.device)
-    sv = torch.zeros(2 * c, dtype=torch.float64, device=x.device)
-    sx, npos = sv[:c], sv[c:]
+    sx = torch.zeros(c, dtype=torch.float64, device=x.device)
     with _timed("gram" if not DETAIL[0] else "gram M%d C%d" % (m, c), 2.0 * m * c * c, 2.0 * x.numel(), 0.0):
-        check(lib().maai_gram(_p(x), m, c, _p(xs), _p(xt), x_relu, _p(g), _p(sx), _p(npos), _stream()), "maai_gram")
-    return g, sx, npos
+        check(lib().maai_gram(_p(x), m, c, _p(xs), _p(xt), x_relu, _p(g), _p(sx), None, _stream()), "maai_gram")
+    return g, sx
 
 
-def conv_dfold(g, y2, wcat, cn, mean2, s2, t2, dx=None):
-    """The folded 64 -> 256 unit's data gradient (csrc/conv_dfold.hip): dx = ([g | relu(bn2(y2))] Wcat^T + cn) * [a2 > 0] with
+def conv_dfold(g, y2, wcat, cn, mean2, s2, t2, dx=None, dg=None):
+    """The folded 64 -> 256 unit's data gradient (csrc/conv_dfold.hip): dx = ([g | relu(bn2(y2))] Wcat^T + cn + dg*a2) * [a2 > 0] with
     the unit below's BatchNorm-backward partial sums -> (dx [.., 64], slab [rows, 2, 64]).  ``dx`` given: += in place."""
-    _gpu(g, y2, wcat, cn, mean2, s2, t2, dx)
+    _gpu(g, y2, wcat, cn, mean2, s2, t2, dx, dg)
     if not (g.dtype == y2.dtype == wcat.dtype == torch.bfloat16) or g.shape[-1] != 256 or y2.shape[-1] != 64 or \
             y2.shape[:-1] != g.shape[:-1] or tuple(wcat.shape) != (64, 1, 1, 320):
         raise MaaiError("conv_dfold: g [..,256], y2 [..,64] and Wcat [64,1,1,320] in bf16")
@@ -837,7 +878,7 @@ def conv_dfold(g, y2, wcat, cn, mean2, s2, t2, dx=None):
     slab = torch.empty((rows, 2, 64), dtype=torch.float32, device=g.device)
     nm = "conv_igemm" if not DETAIL[0] else "conv_igemm[dfold] M%d Cin320 Cout64 k1x1 s1 os1 acc%d" % (m, 1 if acc else 0)
     with _timed(nm, 2.0 * m * 320 * 64, 2 * (g.numel() + (3 if acc else 2) * y2.numel() + wcat.numel()), 2 * (g.numel() + y2.numel())):
-        check(lib().maai_conv_dfold(_p(g), _p(y2), _p(wcat), _p(cn), _p(mean2), _p(s2), _p(t2), _p(dx), _p(slab), m, 1 if acc else 0,
+        check(lib().maai_conv_dfold(_p(g), _p(y2), _p(wcat), _p(cn), _p(dg), _p(mean2), _p(s2), _p(t2), _p(dx), _p(slab), m, 1 if acc else 0,
                                     _stream()), "maai_conv_dfold")
     return dx, slab
 

@@ -86,6 +86,8 @@ def contrastive_loss(hidden1, hidden2, hidden_norm=True, temperature=1.0, local_
     """Reference signature and returns (Objective.py:17-81): (loss, logits_ab [B,N],
     labels [B,2N] int64 one-hot).  ``local_rank`` is the GLOBAL rank, as the driver
     passes it (Contrastive_Learning.py:688)."""
+    from . import engine
+    engine.flush_overlap()   # (a no-grad forward still in flight on the side stream: its output is read from here on)
     assert hidden1.shape == hidden2.shape
     loss, logits = _NTXentFn.apply(hidden1, hidden2, bool(hidden_norm), float(temperature), int(local_rank), int(world_size))
     b = hidden1.shape[0]

@@ -6,6 +6,7 @@ import torch
 
 from . import kernels as K
 from ._lib import MaaiError
+from . import engine
 from .engine import bump_weight_epoch
 
 
@@ -18,6 +19,7 @@ class HipAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        engine.flush_overlap()
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -66,6 +68,7 @@ class HipSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        engine.flush_overlap()
         loss = None
         if closure is not None:
             with torch.enable_grad():

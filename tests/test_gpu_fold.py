@@ -8,7 +8,7 @@ The folded path is NOT bit-identical to the unfolded one (y is never rounded to 
 here against an fp64 torch-autograd evaluation of the same unit on the same bf16 inputs, with the unfolded HIP path beside
 it as the yardstick: the folded gradients must be at least as close to fp64 as 1.5 x the unfolded path's error + 2^-8 of
 the gradient's scale (the bf16 storage rounding of the result itself); measured: dW and dgamma 100-1000 x closer (3e-6 vs 3e-3),
-dx equal (4-6e-3), the unit below's BatchNorm-backward sums 2-4 x further (see the comment at the assertion)."""
+dx equal (4-6e-3), the unit below's BatchNorm-backward sums 1.0-2.2 x (see the comment at the assertion)."""
 import pytest
 import torch
 
@@ -51,19 +51,28 @@ def test_fold_algebra_kernels_match_fp64(E, cout, cin):
     ref = k1.double()[:, None] * g1.double() - k2.double()[:, None] * sx[:cin][None, :] - k3.double()[:, None] * (wd @ gram.double())
     assert (dw.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
     npix = 5000.0
-    npos = (torch.rand(cin, generator=g, dtype=torch.float64) * 3000 + 1000).cuda()
-    wf, tn, cn = K.fold_dgrad_weights(w, k1, k2, k3, s1, sx, npix, npos=npos)
-    assert tuple(wf.shape) == (cin, 1, 1, cout) and tuple(tn.shape) == (cin, 1, 1, cin)
     ref_wf = (k1[:, None] * w.float()).t().contiguous()
-    assert torch.equal(wf.reshape(cin, cout), ref_wf.bfloat16())
-    ref_t = -(wd.t() @ (k3.double()[:, None] * wd))
-    assert (tn.reshape(cin, cin).double() - ref_t.t()).abs().max() <= 2.0 ** -8 * ref_t.abs().max()   # bf16 result: half an ulp = 2^-9
-    # the constant: -(k2 W) minus the pixel mean of what the two roundings add to dx[:, k]
-    dt = tn.reshape(cin, cin).double() - ref_t.t()
-    off = dt - torch.diag(torch.diagonal(dt))
-    comp = ((wf.reshape(cin, cout).double() - ref_wf.double()) @ s1 + off @ sx[:cin]) / npix + torch.diagonal(dt) * sx[:cin] / npos
-    ref = -(k2.double()[None, :] @ wd).reshape(cin) - comp
-    assert (cn.double() - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-9
+    ref_t = -(wd.t() @ (k3.double()[:, None] * wd))          # [j][k] (symmetric)
+    for cat in (False, True):
+        if cat:
+            wcat, cn, dg = K.fold_dgrad_weights(w, k1, k2, k3, s1, sx, npix, cat=True)
+            assert tuple(wcat.shape) == (cin, 1, 1, cout + cin)
+            wf, tn = wcat.reshape(cin, cout + cin)[:, :cout], wcat.reshape(cin, cout + cin)[:, cout:]
+            # T's diagonal is NOT in the bf16 matrix: it comes back in fp32
+            assert float(torch.diagonal(tn).abs().max()) == 0.0
+            assert (dg.double() - torch.diagonal(ref_t)).abs().max() <= 2e-5 * torch.diagonal(ref_t).abs().max()
+        else:
+            wf, tn, cn = K.fold_dgrad_weights(w, k1, k2, k3, s1, sx, npix)
+            wf, tn = wf.reshape(cin, cout), tn.reshape(cin, cin)
+        assert torch.equal(wf, ref_wf.bfloat16())
+        dt = tn.double() - ref_t.t()
+        if cat:
+            dt = dt - torch.diag(torch.diagonal(dt))
+        assert dt.abs().max() <= 2.0 ** -8 * ref_t.abs().max()   # bf16 result: half an ulp = 2^-9
+        # the constant: -(k2 W) minus the pixel mean of what the two roundings add to dx[:, k]
+        comp = ((wf.double() - ref_wf.double()) @ s1 + dt @ sx[:cin]) / npix
+        ref = -(k2.double()[None, :] @ wd).reshape(cin) - comp
+        assert (cn.double() - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-9
 
 
 def _unit(E, n, h, w_, cin, cout, seed, lazy=False):
@@ -142,13 +151,13 @@ def test_folded_unit_backward_against_fp64(E, shape):
         cos = torch.nn.functional.cosine_similarity(f, r, dim=0).item()
         print("%s %s: folded %.3e  unfolded %.3e  cos %.6f" % ("x".join(map(str, shape)), nm, ef, eu, cos))
         if nm == "sums below":
-            # The one quantity the folded path gives up accuracy on (measured 0.4-1.3e-2 of its largest entry against the
-            # unfolded path's 0.2-0.4e-2).  These sums cancel almost completely (sum_p dy = 0 before the ReLU mask), and the
-            # bf16 rounding of the folded WEIGHTS perturbs dx coherently over the pixels where the rounding of dy (unfolded)
-            # is independent per element; the pixel MEAN of that perturbation is taken out of the constant (fold_wf_kernel),
-            # what is left is its correlation with the mask.
-            assert cos > 0.999, (nm, cos)
-            assert ef <= 4.0 * eu + 2.0 ** -8, (nm, ef, eu)
+            # These sums cancel almost completely (sum_p dy = 0 before the ReLU mask): they are where a COHERENT error shows.  The
+            # bf16 rounding of the folded weights is one (the same weight error meets every pixel) — its pixel mean is taken out
+            # of the constant (fold_wf_kernel), and the one large entry per row, T's diagonal, which multiplies the very x_k the
+            # mask and the second sum are made of, never enters bf16 (fold_t_kernel's dg, added in fp32 in the epilogue).
+            # Measured with both: 3.2-5.3e-3 of the largest entry, against 2.0-4.5e-3 unfolded (without them: 1-3e-2).
+            assert cos > 0.9999, (nm, cos)
+            assert ef <= 2.0 * eu + 2.0 ** -8, (nm, ef, eu)
             continue
         assert cos > 0.9999, (nm, cos)
         assert ef <= 1.5 * eu + 2.0 ** -8, (nm, ef, eu)
@@ -187,7 +196,9 @@ def test_folded_unit_backward_in_a_projection_block(E):
         for nm, f, un in [("dx", a[0], b[0])] + [(n, a[1][n], b[1][n]) for n in a[1]]:
             f, un = f.double().reshape(-1), un.double().reshape(-1)
             cos = torch.nn.functional.cosine_similarity(f, un, dim=0).item()
-            assert cos > 0.9995, (inp, planes, nm, cos)
+            # (BatchNorm biases: their gradient IS a BatchNorm-backward first sum — a sum that cancels almost completely, which
+            #  each of the two paths gets to ~4e-3 of its largest entry: two such estimates agree to ~0.999)
+            assert cos > (0.999 if nm.endswith(".bias") else 0.9995), (inp, planes, nm, cos)
             assert abs(f.norm().item() / un.norm().item() - 1) < 1e-2, (inp, planes, nm)
 
 
@@ -256,9 +267,8 @@ def test_gram_kernel_against_fp64(E, m, c, xf):
     else:
         x = y
         xm = y.double().reshape(m, c)
-    gram, sx, npos = K.gram(x)
+    gram, sx = K.gram(x)
     torch.cuda.synchronize()
-    assert torch.equal(npos, (xm > 0).double().sum(0))
     ref = xm.t() @ xm
     assert (gram.double() - ref).abs().max() <= 2e-5 * ref.abs().max()
     rs = xm.sum(0)
@@ -280,16 +290,63 @@ def test_dfold_kernel_against_fp64(E, m, acc):
     t2 = (torch.randn(64, generator=g) * 0.3).cuda()
     mean2 = torch.randn(64, generator=g).cuda()
     prev = torch.randn(1, 1, m, 64, generator=g).cuda().bfloat16()
-    dx, slab = K.conv_dfold(gg, y2, wcat, cn, mean2, s2, t2, dx=prev.clone() if acc else None)
+    dg = (torch.randn(64, generator=g) * 0.5).cuda()
+    dx, slab = K.conv_dfold(gg, y2, wcat, cn, mean2, s2, t2, dx=prev.clone() if acc else None, dg=dg)
     sums = K.reduce_partials(slab)
     torch.cuda.synchronize()
     a2 = K.bn_act_fwd(y2, s2, t2, None, True).double().reshape(m, 64)
     lin = torch.cat([gg.double().reshape(m, 256), a2], 1) @ wcat.double().reshape(64, 320).t() + cn.double()
+    lin = lin.bfloat16().double() + dg.double() * a2     # (the kernel rounds acc + cn to bf16, then adds the fp32 terms)
     if acc:
-        lin = lin.bfloat16().double() + prev.double().reshape(m, 64)   # (the kernel rounds acc + cn to bf16 before adding)
+        lin = lin + prev.double().reshape(m, 64)
     pos = (y2.float().reshape(m, 64) * s2 + t2) > 0
     ref = lin * pos
     got = dx.double().reshape(m, 64)
-    assert (got - ref).abs().max() <= 2.0 ** -7 * ref.abs().max()
+    assert (got - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()
     rs = torch.cat([got.sum(0), (got * (y2.double().reshape(m, 64) - mean2.double())).sum(0)])
     assert (sums - rs).abs().max() <= 1e-4 * rs.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 28, 28, 512, 128, 0), (8, 56, 56, 512, 128, 1), (8, 28, 28, 1024, 256, 0), (16, 14, 14, 2048, 512, 1),
+                                   (1, 9, 11, 256, 64, 0)], ids=lambda s: "x".join(map(str, s)))
+def test_two_source_data_gradient_launch(E, shape):
+    """The folded unit's data gradient in ONE launch: the A operand is the channel concatenation [g | x] of two tensors read
+    in place (maai_conv_epilogue.x2 / cin1) and a per-channel constant is added before rounding (bias) — ring kernel (128-
+    and 256-row tiles) and ping-pong kernel.  Bit-identical to the same launch on a materialised concatenation (same K
+    order), and equal to fp64 within the bf16 rounding of the result."""
+    from maai_hip import kernels as K
+    n, h, w_, c1, c2, acc = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    a = torch.randn(n, h, w_, c1, generator=g).cuda().bfloat16()
+    b = torch.relu(torch.randn(n, h, w_, c2, generator=g)).cuda().bfloat16()
+    wcat = (torch.randn(c2, 1, 1, c1 + c2, generator=g) / (c1 + c2) ** 0.5).cuda().bfloat16()
+    bias = (torch.randn(c2, generator=g) * 0.2).cuda()
+    y2 = torch.randn(n, h, w_, c2, generator=g).cuda().bfloat16()
+    mean = torch.randn(c2, generator=g).cuda()
+    s2 = (torch.rand(c2, generator=g) + 0.5).cuda()
+    t2 = (torch.randn(c2, generator=g) * 0.3).cuda()
+    prev = torch.randn(n, h, w_, c2, generator=g).cuda().bfloat16()
+    dg = (torch.randn(c2, generator=g) * 0.3).cuda()
+    cat = torch.cat([a, b], dim=3).contiguous()
+    res = []
+    for two in (True, False):
+        out = prev.clone() if acc else torch.empty_like(prev)
+        if two:
+            rows = K.conv2d_stats_rows(a, wcat, 1, 0, 0, x2=b)
+            slab = torch.empty((rows, 2, c2), dtype=torch.float32, device="cuda")
+            K.conv2d_store_reduce(a, wcat, 1, 0, 0, out, slab, y2, mean, s2, t2, None, accumulate=bool(acc), x2=b, bias=bias, diag=dg)
+        else:
+            rows = K.conv2d_stats_rows(cat, wcat, 1, 0, 0)
+            slab = torch.empty((rows, 2, c2), dtype=torch.float32, device="cuda")
+            K.conv2d_store_reduce(cat, wcat, 1, 0, 0, out, slab, y2, mean, s2, t2, None, accumulate=bool(acc), bias=bias, diag=dg)
+        res.append((out, K.reduce_partials(slab)))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    m = n * h * w_
+    lin = cat.double().reshape(m, c1 + c2) @ wcat.double().reshape(c2, c1 + c2).t() + bias.double()
+    act = K.bn_act_fwd(y2, s2, t2, None, True).double().reshape(m, c2)
+    lin = lin.bfloat16().double() + dg.double() * act          # (acc + bias is rounded to bf16, the fp32 terms follow)
+    if acc:
+        lin = lin + prev.double().reshape(m, c2)
+    ref = lin * ((y2.float().reshape(m, c2) * s2 + t2) > 0)
+    assert (res[0][0].double().reshape(m, c2) - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()

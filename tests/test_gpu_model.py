@@ -215,6 +215,62 @@ def test_resnet18_cfg1_literal_fp32_against_reference_golden(mods, golden_dir):
     np.testing.assert_allclose(gn, G["gnorms"], rtol=2e-2)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("arch,cm,shape", [("resnet18", 1, (16, 3, 32, 32)), ("resnet50", 4, (8, 12, 30, 30))])
+def test_overlapped_views_equal_sequential_forwards(mods, golden_dir, arch, cm, shape, prec):
+    """the no-grad view-1 forward on a side HIP stream under the gradient-carrying view-2 forward
+    (engine.set_overlap_views; Contrastive_Learning.py:638-700 semantics as bench.py runs them).  Both forwards defer their
+    BatchNorm buffer updates and ONE launch applies them in program order after the join: embeddings, loss, running_mean /
+    running_var / num_batches_tracked of EVERY layer are bit-identical to the two forwards run one after the other — two steps,
+    so that the second step's forwards start from buffers the first one's join wrote.  (ResNet-18 fp32: that sequential run is
+    the one test_resnet18_cfg1_fp32_against_reference_golden holds against the reference.)"""
+    from maai_hip import engine
+    engine.set_precision(prec)
+    head_in = (512 if arch == "resnet18" else 2048) * 16
+    x1 = _u8(100, shape).float().cuda()
+    x2 = _u8(101, shape).float().cuda()
+    res = {}
+    try:
+        for tag in ("sequential", "overlapped"):
+            engine.set_overlap_views(tag == "overlapped")
+            m = _build(mods, arch, cm, head_in, shape[0], shape[2:], 0.25)
+            m.train()
+            outs = []
+            for step in range(2):
+                with torch.no_grad():
+                    h1 = m.forward_tensor(x1)
+                if tag == "overlapped":
+                    assert engine._OVL["pending"] is not None      # in flight on the side stream, nothing joined yet
+                h2 = m.forward_tensor(x2)
+                assert engine._OVL["pending"] is None
+                loss, _, _ = mods["Objective"].contrastive_loss(hidden1=h1.data, hidden2=h2, temperature=0.5)
+                m.zero_grad(set_to_none=True)
+                loss.backward()
+                outs += [h1.detach().clone(), h2.detach().clone(), loss.detach().clone()]
+            torch.cuda.synchronize()
+            res[tag] = (outs, {n: b.clone() for n, b in m.named_buffers()})
+    finally:
+        engine.set_overlap_views(False)
+    for a, b in zip(res["sequential"][0], res["overlapped"][0]):
+        assert torch.equal(a, b)
+    assert len(res["sequential"][1]) > 50
+    for n, b in res["sequential"][1].items():
+        assert torch.equal(res["overlapped"][1][n], b), n
+    assert int(res["overlapped"][1]["f.bn1.num_batches_tracked"]) == 4
+    # a no-grad forward that nothing follows: the loss call joins it
+    engine.set_overlap_views(True)
+    try:
+        m = _build(mods, arch, cm, head_in, shape[0], shape[2:], 0.25)
+        m.train()
+        with torch.no_grad():
+            h1 = m.forward_tensor(x1)
+        l, _, _ = mods["Objective"].contrastive_loss(hidden1=h1, hidden2=h1.flip(0), temperature=0.5)
+        assert engine._OVL["pending"] is None and torch.isfinite(l).item()
+        assert int(m.f.bn1.num_batches_tracked) == 1
+    finally:
+        engine.set_overlap_views(False)
+
+
 def test_bf16_production_path_end_to_end_resnet18(mods):
     """bf16 storage / fp32 accumulate vs the oracle rounding at the same points, end to end.  Residual
     blocks amplify the 2^-9 rounding noise (tests/test_oracle_golden.py::test_bf16_storage_mode_close_to_fp32;
