@@ -12,6 +12,7 @@
 // Epilogue as EMODE 6 of conv_igemm.h on the wave's private C area: y2 (and the previous dx) in the row-store layout were
 // requested before the K loop.
 #include "conv_igemm.h"
+#include <stdlib.h>
 
 struct DfoldArgs {
   const void* g;       // [M][256]
@@ -33,11 +34,15 @@ __device__ __forceinline__ void dfold_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");   // (lgkmcnt(0): the ring invariant, as in conv_pws.hip)
 }
 
-template <bool ACC>
-__global__ __launch_bounds__(256, 3) void conv_dfold_kernel(DfoldArgs a) {
+// RESIDENT: all ten weight stages (40 KB) are requested at once, right behind the operand loads, and the K loop runs behind ONE
+// wait + barrier instead of ten (the ring version waits for an L2 round trip and a barrier per 8 MFMAs of a wave).
+// (two workgroups per CU: at three the 170-register budget spilled 24-42 registers per lane to scratch — 25-45 % extra memory
+//  traffic on a kernel that has nothing but memory traffic; two keep 196 KB of operand loads in flight per CU)
+template <bool ACC, bool RESIDENT>
+__global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
   typedef bf16_t T;
   constexpr int TM = 2, BM = 128, KC1 = 256, KC2 = 64, K = KC1 + KC2, KT1 = KC1 / 32, KT2 = KC2 / 32, KT = KT1 + KT2;
-  constexpr int BN = 64, TN = 4, STAGE = BN * 64, DIST = 3, NSLOT = DIST + 2, RING = NSLOT * STAGE;
+  constexpr int BN = 64, TN = 4, STAGE = BN * 64, DIST = RESIDENT ? 10 : 3, NSLOT = RESIDENT ? 10 : DIST + 2, RING = NSLOT * STAGE;
   constexpr int LDC = BN + 8, CW = 16 * LDC * 2, CPR = 8, RPI = 8, NIT = 2;
   typedef Mma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,14 +151,20 @@ __global__ __launch_bounds__(256, 3) void conv_dfold_kernel(DfoldArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   int slot = 0;
+  if constexpr (RESIDENT) {
+    dfold_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();   // every stage has landed
+  }
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt) {
-    const int rem = KT - 1 - kt;
-    if (rem >= DIST - 1) dfold_wait_vm<DIST - 1>();
-    else if (rem == 1) dfold_wait_vm<1>();
-    else dfold_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (issued < KT) issue_b();   // into the slot read two steps ago
+    if constexpr (!RESIDENT) {
+      const int rem = KT - 1 - kt;
+      if (rem >= DIST - 1) dfold_wait_vm<DIST - 1>();
+      else if (rem == 1) dfold_wait_vm<1>();
+      else dfold_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if (issued < KT) issue_b();   // into the slot read two steps ago
+    }
     const char* sb = smem + slot * STAGE + foff;
     frag_t bfr[TN];
 #pragma unroll
@@ -255,18 +266,22 @@ extern "C" int maai_conv_dfold(const void* g, const void* y2, const void* w, con
   DfoldArgs a;
   a.g = g; a.y2 = y2; a.w = w; a.cn = cn; a.dg = dg; a.mean2 = mean2; a.s2 = s2; a.t2 = t2; a.dx = dx; a.slab = slab; a.M = M;
   a.nMB = (int)((M + 127) / 128);
-  constexpr int lds = 5 * 64 * 64 + 4 * 16 * 72 * 2 + 8 * 64 * 4 + 2 * 64 * 4;
+  static const bool resident = !(getenv("MAAI_DFOLD_RESIDENT") && atoi(getenv("MAAI_DFOLD_RESIDENT")) == 0);   // A/B knob
+  const int lds = (resident ? 10 : 5) * 64 * 64 + 4 * 16 * 72 * 2 + 8 * 64 * 4 + 2 * 64 * 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  static int attr[2][64] = {{0}};
+  static int attr[4][64] = {{0}};
+#define MAAI_DFOLD_LAUNCH(ACCV, RESV, SLOT)                                                                          \
+  do {                                                                                                               \
+    maai_ensure_lds(reinterpret_cast<const void*>(&conv_dfold_kernel<ACCV, RESV>), lds, attr[SLOT]);                 \
+    MAAI_NOTE_KERNEL(conv_dfold_kernel<ACCV, RESV>);                                                                 \
+    hipLaunchKernelGGL((conv_dfold_kernel<ACCV, RESV>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);               \
+  } while (0)
   if (accumulate) {
-    maai_ensure_lds(reinterpret_cast<const void*>(&conv_dfold_kernel<true>), lds, attr[0]);
-    MAAI_NOTE_KERNEL(conv_dfold_kernel<true>);
-    hipLaunchKernelGGL((conv_dfold_kernel<true>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+    if (resident) MAAI_DFOLD_LAUNCH(true, true, 0); else MAAI_DFOLD_LAUNCH(true, false, 1);
   } else {
-    maai_ensure_lds(reinterpret_cast<const void*>(&conv_dfold_kernel<false>), lds, attr[1]);
-    MAAI_NOTE_KERNEL(conv_dfold_kernel<false>);
-    hipLaunchKernelGGL((conv_dfold_kernel<false>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
+    if (resident) MAAI_DFOLD_LAUNCH(false, true, 2); else MAAI_DFOLD_LAUNCH(false, false, 3);
   }
+#undef MAAI_DFOLD_LAUNCH
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

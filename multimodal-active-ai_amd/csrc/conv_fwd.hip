@@ -173,9 +173,17 @@ static bool pws_selected(const maai_conv_desc* d, const maai_conv_epilogue* epi,
   if (mode == 1 && (getenv("MAAI_CONV_BM") || getenv("MAAI_CONV_BN") || getenv("MAAI_CONV_NSTAGE"))) return false;
   const bool pw1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad_h == 0 && d->pad_w == 0 && d->OHg == d->IH && d->OWg == d->IW;
   if (!(dtype == MAAI_BF16 && pw1 && d->Cout % 64 == 0)) return false;
-  if (d->accumulate || d->out_stride != 1 || d->OH != d->OHg || d->OW != d->OWg) return false;
-  if (epi && ((epi->mode != MAAI_EPI_STORE && !((epi->mode == MAAI_EPI_STATS_ONLY || epi->mode == MAAI_EPI_BN_ACT) && !epi->xb)) || epi->a2 || epi->pre_x)) return false;
+  if (d->out_stride != 1 || d->OH != d->OHg || d->OW != d->OWg) return false;
   if (!(d->Cin == 64 || d->Cin == 128 || d->Cin == 256)) return false;
+  if (epi && epi->mode == MAAI_EPI_DGRAD_REDUCE) {
+    // the sum-only data-gradient epilogue with a 1-bit mask (the consumer of the gradient is a folded unit), store or
+    // accumulate: conv1's data gradient of the identity blocks of stages 1-3 (64 -> 256, 128 -> 512, 256 -> 1024)
+    static const bool off = getenv("MAAI_PWS_DGRAD") && atoi(getenv("MAAI_PWS_DGRAD")) == 0;   // A/B knob
+    return !off && !epi->t && epi->mask_bits && !epi->xs && !epi->xb && !epi->a2 && !epi->pre_x && !epi->x2 && !epi->bias && !epi->diag &&
+           !epi->sum_increment && d->Cout >= 2 * d->Cin;
+  }
+  if (d->accumulate) return false;
+  if (epi && ((epi->mode != MAAI_EPI_STORE && !((epi->mode == MAAI_EPI_STATS_ONLY || epi->mode == MAAI_EPI_BN_ACT) && !epi->xb)) || epi->a2 || epi->pre_x)) return false;
   if (epi && epi->mode == MAAI_EPI_BN_ACT && d->Cout > 1024) return false;   // (its coefficient table lives in the statistics scratch)
   // ... and every forward launch with 256 input channels (conv1 of layer 1's blocks and of layer2.0: 1-7 % slower than the
   // ring kernel there): the chained launch of conv_chain.hip, which replaces the join-on-load form of those launches in
@@ -401,7 +409,7 @@ extern "C" int maai_conv2d_igemm_fused(const maai_conv_desc* d, const void* x, c
     return maai_conv_pp_launch(a, st);
   }
   if (pws) {
-    if (!relu_mask) return maai_conv_pws_launch(a, st);
+    if (!relu_mask || emode == MAAI_EPI_DGRAD_REDUCE) return maai_conv_pws_launch(a, st);
     plan.bm = 128;   // the slab rows promised for this shape (a masked launch never carries a join: 128-row tiles)
     sel.bm = 128;
     plan.nMB = (a.M + 127) / 128;

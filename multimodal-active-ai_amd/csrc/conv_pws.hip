@@ -35,12 +35,27 @@ __device__ __forceinline__ void wait_vm() {
 // EMODE 0: plain store (+ statistics slab); 1: statistics slab only (the chained launch of conv_chain.hip recomputes the tensor);
 // 2: MAAI_EPI_BN_ACT — frozen statistics: out = act(r(y)*scale + shift (+ residual)) applied to the bf16-rounded tile on its
 // way out (the arithmetic of maai_bn_act_fwd on the stored tensor: bit-identical to launch + pass), no raw output in HBM.
+// 6: MAAI_EPI_DGRAD_REDUCE for the data gradient of an expanding pointwise layer whose consumer is FOLDED (round 4: conv1's data
+// gradient flowing into the block's shortcut gradient, resnet.py:101 backwards): out = (acc (+ out)) * mask bit, one slab row per
+// 128 pixels with the sum of the stored values (the first BatchNorm-backward sum; the second is not wanted: the unit below
+// never reads its raw output, engine._FOLD) — RES = accumulate (the previous content is the "residual", read from the output
+// tensor itself a column tile ahead), the mask bytes travel with it.
 // RES (EMODE 2): a residual tensor is added; its tile is requested a whole column tile ahead (before the K loop), and the
 // loads enter the vmcnt bookkeeping next to the stores they follow.  BITS (EMODE 2): the 1-bit ReLU mask of the stored output
 // goes to a.x_bits (one byte per 16-byte chunk, the layout of maai_bn_act_fwd_mask) — the training forward of a unit whose
 // raw output is never stored (engine._FOLD) keeps it for the backward pass.
+// Workgroups per CU (the register budget): the epilogues that hold a prefetched residual / previous-content tile (EMODE 2 + RES,
+// EMODE 6) need ~40 more registers than the plain store — budgets chosen so that no instantiation on the default path spills
+// (checked with -Rpass-analysis=kernel-resource-usage; round 4 found 6-18 spilled registers per lane on three of them).
+template <int KC, int BN, int XF, int EMODE, bool RES>
+constexpr int pws_min_blocks() {
+  if (BN == 128) return KC == 256 ? 2 : 3;
+  if (KC == 256) return (XF == 2 || (EMODE == 6 && RES)) ? 2 : 3;
+  if (KC == 128 && RES && (EMODE == 2 || EMODE == 6)) return 3;
+  return 4;
+}
 template <int KC, int BN, int DIST, int XF, int EMODE, bool RES = false, bool BITS = false>
-__global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ? (XF == 2 ? 2 : 3) : 4)) void conv_pws_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (pws_min_blocks<KC, BN, XF, EMODE, RES>())) void conv_pws_kernel(ConvArgs a) {
   typedef bf16_t T;
   constexpr int TM = 2, BM = 64 * TM, TN = BN / 16, KT = KC / 32, BR = BN / 64, STAGE = BN * 64;
   constexpr int LDC = BN + 8;              // private C tile row pitch (elements)
@@ -48,7 +63,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   constexpr int CPR = BN / 8;              // 16-byte chunks per output row of the column tile
   constexpr int RPI = 64 / CPR;            // rows one wave-wide 16-byte access covers
   constexpr int NIT = 16 / RPI;            // such accesses per 16-row group
-  constexpr int NST = (EMODE == 1 ? 0 : TM * NIT) * ((RES ? 2 : 1) + (BITS ? 1 : 0));   // global stores (+ residual loads, + mask bytes) per wave per column tile
+  constexpr int NST = (EMODE == 1 ? 0 : TM * NIT) * ((RES ? 2 : 1) + (BITS ? 1 : 0) + (EMODE == 6 ? 1 : 0));   // global stores (+ residual / previous-content loads, + mask bytes written or read) per wave per column tile
   constexpr int NSLOT = DIST + 2;
   constexpr int RING = NSLOT * STAGE;
   typedef Mma<T>::frag frag_t;
@@ -149,8 +164,24 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
 
   // ---- EMODE 2: scale | shift of all output channels in LDS (the statistics scratch, unused here); residual prefetch ----
   float* ecoef = red;
-  uint4 rv[(EMODE == 2 && RES) ? TM * NIT : 1];
+  uint4 rv[((EMODE == 2 || EMODE == 6) && RES) ? TM * NIT : 1];
+  unsigned mbit[EMODE == 6 ? TM * NIT : 1];
   auto load_res = [&](int ct) {   // the residual tile of column tile ct, in the epilogue's row-store layout
+    if constexpr (EMODE == 6) {
+      const unsigned char* __restrict__ mk = reinterpret_cast<const unsigned char*>(a.mask);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const long long m0 = arow0 + i * 16 + lane / CPR;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          long long m = m0 + it * RPI;
+          if (!full && m >= a.M) m = a.M - 1;   // (unconditional loads keep the vmcnt bookkeeping exact; such rows are never stored)
+          const long long off = m * a.Cout + ct * BN + (lane % CPR) * 8;
+          if constexpr (RES) rv[i * NIT + it] = ld16_nt(y + off);
+          mbit[i * NIT + it] = mk[off >> 3];
+        }
+      }
+    }
     if constexpr (EMODE == 2 && RES) {
       const T* __restrict__ res = reinterpret_cast<const T*>(a.et);
 #pragma unroll
@@ -169,6 +200,7 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
     for (int i = tid; i < 2 * a.Cout; i += 256) ecoef[i] = i < a.Cout ? (a.ep0 ? a.ep0[i] : 1.f) : (a.ep1 ? a.ep1[i - a.Cout] : 0.f);
     load_res(0);   // (issued before any weight stage: older than everything the K loop waits for)
   }
+  if constexpr (EMODE == 6) load_res(0);
 
   // ---- weight stages: stage s = (column tile s / KT, K-step s % KT), 64-byte rows, swizzled like conv_igemm ----
   const int r0 = tid >> 2;
@@ -198,6 +230,14 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
   float* sred = red + ((widu * 4 + (lane >> 4)) * 2) * BN + (lane & 15);
 
   auto finish_stats = [&](int ct) {  // after a barrier that follows the epilogue of column tile ct
+    if constexpr (EMODE == 6) {
+      if (tid < 2 * BN) {
+        const int which = tid / BN, c = tid - which * BN;
+        const float t = which ? 0.f : red[c] + red[2 * BN + c] + red[4 * BN + c] + red[6 * BN + c];   // (the second sum is not reduced here)
+        a.stats[((long long)mb * 2 + which) * a.Cout + ct * BN + c] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if (a.stats && EMODE != 6 && EMODE != 2) {
 #pragma unroll
       for (int o = tid; o < 2 * BN; o += 256) {
@@ -270,6 +310,11 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
         sred[BN + j * 16] = q2.x + q2.y;
       }
     }
+    float dsum[EMODE == 6 ? 8 : 1];
+    if constexpr (EMODE == 6) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum[e] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < (EMODE == 1 ? 0 : TM); ++i) {   // (EMODE 1: statistics only, nothing is stored)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous group's reads of this area are done
@@ -289,7 +334,33 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
       const long long m0 = arow0 + i * 16 + lane / CPR;
       T* dst = y + m0 * a.Cout + ct * BN + (lane % CPR) * 8;
       const T* csrc = reinterpret_cast<const T*>(cw) + (lane / CPR) * LDC + (lane % CPR) * 8;
-      if constexpr (EMODE == 2) {
+      if constexpr (EMODE == 6) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          Vec16<T> v;
+          v.load(csrc + it * RPI * LDC);
+          float fv[8];
+          v.get(fv);
+          if constexpr (RES) {
+            Vec16<T> r;
+            r.raw = rv[i * NIT + it];
+            float fr[8];
+            r.get(fr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fv[e] += fr[e];
+          }
+          const unsigned mb8 = mbit[i * NIT + it];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fv[e] = ((mb8 >> e) & 1u) ? fv[e] : 0.f;
+          v.set(fv);
+          v.get(fv);   // the rounded value being stored is what a separate reduction pass would read back
+          if (full || m0 + it * RPI < a.M) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum[e] += fv[e];
+            v.store(dst + (long long)it * RPI * a.Cout);
+          }
+        }
+      } else if constexpr (EMODE == 2) {
         float q0[8], q1[8];
         {
           const float* cs = ecoef + ct * BN + (lane % CPR) * 8;
@@ -341,6 +412,19 @@ __global__ __launch_bounds__(256, BN == 128 ? (KC == 256 ? 2 : 3) : (KC == 256 ?
     if constexpr (EMODE == 2 && RES) {
       if (ct + 1 < nCT) load_res(ct + 1);   // behind this tile's stores: one package of NST vector-memory operations per epilogue
     }
+    if constexpr (EMODE == 6) {
+      if (ct + 1 < nCT) load_res(ct + 1);
+      // this wave's column sums over its 32 rows: lanes l, l + CPR, ... hold the same channels
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) dsum[e] += __shfl_xor(dsum[e], o);
+      }
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(widu * 2) * BN + lane * 8 + e] = dsum[e];
+      }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -391,6 +475,13 @@ static int pws_k(const ConvArgs& a, hipStream_t st) {
     if (a.et) return a.xs ? launch_pws<KC, BN, DIST, 1, 2, true>(b, st) : launch_pws<KC, BN, DIST, 0, 2, true>(b, st);
     return a.xs ? launch_pws<KC, BN, DIST, 1, 2, false>(b, st) : launch_pws<KC, BN, DIST, 0, 2, false>(b, st);
   }
+  if (a.emode == MAAI_EPI_DGRAD_REDUCE) {
+    if (a.xs || a.xb || a.et || !a.mask || !a.mask_bits || !a.stats) {
+      maai_set_error("conv2d_igemm: the streaming kernel's data-gradient epilogue is the sum-only form with a 1-bit mask");
+      return MAAI_ERR_UNSUPPORTED;
+    }
+    return a.accumulate ? launch_pws<KC, BN, DIST, 0, 6, true>(a, st) : launch_pws<KC, BN, DIST, 0, 6, false>(a, st);
+  }
   if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
   if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
   return launch_pws<KC, BN, DIST, 0, 0>(a, st);
@@ -402,7 +493,10 @@ static int pws_k(const ConvArgs& a, hipStream_t st) {
 int maai_conv_pws_launch(const ConvArgs& a, hipStream_t st) {
   const char* e = getenv("MAAI_PWS_BN");   // experiment knob
   const int forced = e ? atoi(e) : 0;
-  const bool n128 = a.Cout % 128 == 0 && forced != 64 && (forced == 128 || (a.Cin >= 256 && a.Cout >= 512));
+  // (the data-gradient epilogue with accumulate holds a previous-content tile next to the accumulators: at 128 columns and 256
+  //  input channels it spills 12 registers per lane, at 64 columns none)
+  const bool n128 = a.Cout % 128 == 0 && forced != 64 &&
+                    (forced == 128 || (a.Cin >= 256 && a.Cout >= 512 && !(a.emode == MAAI_EPI_DGRAD_REDUCE && a.accumulate)));
   switch (a.Cin) {
     case 64: return n128 ? pws_k<64, 128>(a, st) : pws_k<64, 64>(a, st);
     case 128: return n128 ? pws_k<128, 128>(a, st) : pws_k<128, 64>(a, st);

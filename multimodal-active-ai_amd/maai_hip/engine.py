@@ -1457,7 +1457,7 @@ def block_bwd(entry, dout, grads, dtype, prev=None, presums=None, mask_input=Tru
         #  m*(m*a + b) == m*(a + b) for a 0/1 mask).  The sums for ``prev`` can only ride the second pass, and
         #  only if it rewrites every pixel (stride-1 downsample); otherwise ``prev`` reduces them itself.
         strided = rd.stride != 1
-        if prev is not None and strided and _DGRAD_REDUCE["enabled"] and prev.y is not None:
+        if prev is not None and strided and _DGRAD_REDUCE["enabled"] and (prev.y is not None or (prev.has_res and _fold_static(prev))):
             # stride-2 shortcut: the dense conv1 pass reduces the sums of what it stores, the strided pass those of what
             # it adds on the pixels it touches (sum_increment) — together the sums of the final gradient
             dx, sa = unit_bwd(r1, d, grads, dtype, below=prev, presums=s)

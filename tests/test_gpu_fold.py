@@ -9,6 +9,8 @@ here against an fp64 torch-autograd evaluation of the same unit on the same bf16
 it as the yardstick: the folded gradients must be at least as close to fp64 as 1.5 x the unfolded path's error + 2^-8 of
 the gradient's scale (the bf16 storage rounding of the result itself); measured: dW and dgamma 100-1000 x closer (3e-6 vs 3e-3),
 dx equal (4-6e-3), the unit below's BatchNorm-backward sums 1.0-2.2 x (see the comment at the assertion)."""
+import os
+
 import pytest
 import torch
 
@@ -80,6 +82,7 @@ def _unit(E, n, h, w_, cin, cout, seed, lazy=False):
     needs and the fp64 reference gradients."""
     from maai_hip import kernels as K
     g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)       # (conv2's default initialisation draws from the global generator)
     conv2 = torch.nn.Conv2d(cin, cin, 3, padding=1, bias=False).cuda()
     bn2 = torch.nn.BatchNorm2d(cin).cuda().train()
     conv3 = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
@@ -223,12 +226,15 @@ def test_bn_relu_epilogue_mask_output_equals_the_pass(E, shape, res):
     assert 0.2 < (out > 0).float().mean().item() < 0.8
 
 
-@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 512, 0), (4, 28, 28, 128, 512, 1), (8, 14, 14, 256, 1024, 1), (2, 7, 7, 512, 2048, 1)],
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 512, 0), (4, 28, 28, 128, 512, 1), (8, 14, 14, 256, 1024, 1), (2, 7, 7, 512, 2048, 1),
+                                   (2, 30, 30, 64, 256, 1), (2, 33, 35, 64, 256, 0), (3, 14, 14, 256, 1024, 0), (1, 9, 11, 128, 512, 1)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_sum_only_data_gradient_epilogue(E, shape):
     """The data-gradient epilogue that reduces the BatchNorm-backward sums of the unit BELOW (MAAI_EPI_DGRAD_REDUCE) without
-    that unit's raw output — a folded unit wants sum(g) only: same stored gradient, same first sum, ring and ping-pong kernels,
-    store and accumulate."""
+    that unit's raw output — a folded unit wants sum(g) only: same stored gradient bit for bit, same first sum (to fp32
+    summation order: the expanding layers with 64 / 128 / 256 input channels take the STREAMING kernel's data-gradient
+    epilogue, csrc/conv_pws.hip EMODE 6, whose slab rows cover 128 pixels), ring and ping-pong kernels, store and accumulate,
+    ragged last tiles."""
     from maai_hip import kernels as K
     n, h, w_, cin, cout, acc = shape     # a conv1-like data gradient: dy [.., cin] -> dx [.., cout] (the block input's channels)
     g = torch.Generator().manual_seed(sum(shape))
@@ -247,7 +253,20 @@ def test_sum_only_data_gradient_epilogue(E, shape):
         outs.append((out, K.reduce_partials(slab)))
     torch.cuda.synchronize()
     assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1][:cout], outs[1][1][:cout])
+    assert (outs[0][1][:cout] - outs[1][1][:cout]).abs().max() <= 1e-5 * outs[0][1][:cout].abs().max() + 1e-4
+    # ... and, where the streaming kernel takes the sum-only launch, against the ring kernel forced for the same launch
+    with_env = dict(os.environ)
+    os.environ["MAAI_CONV_PWS"] = "0"
+    try:
+        out = prev.clone() if acc else torch.empty_like(prev)
+        rows0 = K.conv2d_stats_rows(dy, wd, 1, 0, 0)
+        slab = torch.empty((rows0, 2, cout), dtype=torch.float32, device="cuda")
+        K.conv2d_store_reduce(dy, wd, 1, 0, 0, out, slab, None, mean, None, None, bits, accumulate=bool(acc), mask_bits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(out, outs[1][0])
+    finally:
+        os.environ.clear()
+        os.environ.update(with_env)
     ref = (outs[0][0].double()).sum((0, 1, 2))
     assert (outs[1][1][:cout] - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-3
 
@@ -350,3 +369,22 @@ def test_two_source_data_gradient_launch(E, shape):
         lin = lin + prev.double().reshape(m, c2)
     ref = lin * ((y2.float().reshape(m, c2) * s2 + t2) > 0)
     assert (res[0][0].double().reshape(m, c2) - ref).abs().max() <= 2.0 ** -8 * ref.abs().max()
+
+
+def test_folded_sums_below_over_seeds(E, record_property):
+    """The distribution, over ten random units, of the folded path's error on the one sensitive quantity (the unit below's
+    BatchNorm-backward sums) against the unfolded path's, both vs fp64 — reported, and bounded at the level this suite has seen."""
+    rows = []
+    for seed in range(10):
+        u = _unit(E, 4, 56, 56, 64, 256, seed=1000 + seed, lazy=True)
+        ref = _reference(u)[4]
+        f = _run(E, u, True)[4].double()
+        un = _run(E, u, False)[4].double()
+        scale = ref.abs().max().item()
+        rows.append(((f - ref.to(f.device)).abs().max().item() / scale, (un - ref.to(f.device)).abs().max().item() / scale))
+    ef = sorted(r[0] for r in rows)
+    eu = sorted(r[1] for r in rows)
+    msg = "sums below, 10 units 4x56x56 64->256 (lazy input): folded median %.2e max %.2e; unfolded median %.2e max %.2e" % (ef[5], ef[-1], eu[5], eu[-1])
+    print(msg)
+    record_property("fold_sums_below", msg)
+    assert ef[5] <= 3.0 * eu[5] + 2.0 ** -8 and ef[-1] <= 0.05, msg
