@@ -375,6 +375,14 @@ int maai_fold_dgrad_w(const void* w, const float* k1, const float* k2, const flo
  *   BatchNorm backward). */
 int maai_gram(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* gram, double* sx, double* npos,
               void* stream);
+/* Deterministic form: pgram [maai_gram_partial_rows(M, C)][C][C] and psx [rows][C] (fp32) are WRITTEN, one row per workgroup
+ * column, no atomics; summed by maai_reduce_partials they are bit-reproducible and may feed forward statistics:
+ * maai_fold_stats: sums[c] = W[c] . sx, sums[Cout + c] = W[c] Gram W[c]^T (fp64; gram [Cin][Cin], sx [Cin] fp64) — the BatchNorm
+ * statistics of y = x W^T without computing y, in the layout maai_bn_finalize takes (the chained block boundaries of layer 1). */
+int maai_gram_partial_rows(long long M, int C);
+int maai_gram_partials(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* pgram, float* psx,
+                       void* stream);
+int maai_fold_stats(const void* w, const double* gram, const double* sx, double* sums, int Cout, int Cin, void* stream);
 long long maai_conv_dfold_rows(long long M);
 int maai_conv_dfold(const void* g, const void* y2, const void* w, const float* cn, const float* dg, const float* mean2, const float* s2,
                     const float* t2, void* dx, float* slab, long long M, int accumulate, void* stream);

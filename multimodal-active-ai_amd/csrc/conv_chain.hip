@@ -18,6 +18,7 @@
 // through one LDS-DMA ring of DIST + 2 slots.  vmcnt bookkeeping is dynamic: a uniform counter of vector-memory
 // instructions issued, the value it had after each stage's issue, and a switch onto the immediate forms.
 #include "conv_igemm.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ void chain_wait_vm(int n) {   // wait until at most n vector-memory operations are outstanding
   switch (n < 0 ? 0 : (n > 23 ? 23 : n)) {                // (waiting for fewer than allowed is always safe)
@@ -319,9 +320,8 @@ __global__ __launch_bounds__(256, 3) void conv_chain_kernel(ConvArgs a) {
   finish_stats(nCT2 - 1);
 }
 
-template <int KC1, bool PROJ, bool BITS, bool KEEPY>
-static int launch_chain(ConvArgs a, hipStream_t st) {
-  constexpr int DIST = 3;
+template <int KC1, bool PROJ, bool BITS, bool KEEPY, int DIST>
+static int launch_chain_d(ConvArgs a, hipStream_t st) {
   constexpr int lds = (DIST + 2) * 64 * 64 + 4 * 16 * 72 * 2 + 32 * 64 * 4 + (2 * KC1 + 16 * KC1) * 4;
   a.nMB = (int)((a.M + 127) / 128);
   static int attr_lds[64] = {0};
@@ -330,6 +330,14 @@ static int launch_chain(ConvArgs a, hipStream_t st) {
   hipLaunchKernelGGL((conv_chain_kernel<KC1, DIST, PROJ, BITS, KEEPY>), dim3((unsigned)a.nMB), dim3(256), lds, st, a);
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
+}
+
+// DIST = weight stages in flight ahead of the one being multiplied (ring of DIST + 2 slots of 4 KB).  MAAI_CHAIN_DIST = 3 | 5 (A/B knob).
+template <int KC1, bool PROJ, bool BITS, bool KEEPY>
+static int launch_chain(ConvArgs a, hipStream_t st) {
+  static const int dist = getenv("MAAI_CHAIN_DIST") ? atoi(getenv("MAAI_CHAIN_DIST")) : 3;
+  if (dist == 5) return launch_chain_d<KC1, PROJ, BITS, KEEPY, 5>(a, st);
+  return launch_chain_d<KC1, PROJ, BITS, KEEPY, 3>(a, st);
 }
 
 template <int KC1, bool PROJ>

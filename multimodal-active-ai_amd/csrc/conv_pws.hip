@@ -444,9 +444,8 @@ static int launch_pws(ConvArgs a, hipStream_t st) {
   return MAAI_OK;
 }
 
-template <int KC, int BN>
-static int pws_k(const ConvArgs& a, hipStream_t st) {
-  constexpr int DIST = KC == 256 ? 3 : 2;
+template <int KC, int BN, int DIST>
+static int pws_kd(const ConvArgs& a, hipStream_t st) {
   if (a.emode == MAAI_EPI_STATS_ONLY) {
     if (a.xb) {
       maai_set_error("conv2d_igemm: the statistics-only streaming launch takes a plain or normalised-on-load input");
@@ -485,6 +484,15 @@ static int pws_k(const ConvArgs& a, hipStream_t st) {
   if (a.xb) return launch_pws<KC, BN, DIST, 2, 0>(a, st);
   if (a.xs) return launch_pws<KC, BN, DIST, 1, 0>(a, st);
   return launch_pws<KC, BN, DIST, 0, 0>(a, st);
+}
+
+// DIST = weight stages in flight ahead of the one being multiplied.  MAAI_PWS_DIST = 0 (default: 3 for 256 input channels, else 2)
+// | 1 (one more: 4 / 3) — A/B knob.
+template <int KC, int BN>
+static int pws_k(const ConvArgs& a, hipStream_t st) {
+  static const int more = getenv("MAAI_PWS_DIST") ? atoi(getenv("MAAI_PWS_DIST")) : 0;
+  if (more == 1) return pws_kd<KC, BN, (KC == 256 ? 4 : 3)>(a, st);
+  return pws_kd<KC, BN, (KC == 256 ? 3 : 2)>(a, st);
 }
 
 // One 128-row tile per workgroup (the statistics slab's rows).  Column tile: 64 output channels (4 workgroups per CU; 3 for Cin 256) except for Cin >= 256

@@ -110,6 +110,41 @@ __global__ __launch_bounds__(256) void fold_wf_kernel(const bf16_t* __restrict__
   if (threadIdx.x == 0) cn[k] = -red[0] - (float)((double)red2[0] * inv_n) - ct[k];
 }
 
+// Forward BatchNorm statistics of y = x W^T WITHOUT computing y: sum_p y[p][c] = W[c] . sx,  sum_p y[p][c]^2 = W[c] Gram W[c]^T
+// (fp64 on the fp64 sums of a deterministic Gram pass, maai_gram_partials): sums[c] | sums[Cout + c] in the layout
+// maai_bn_finalize takes.  One wave per output channel.
+__global__ __launch_bounds__(256) void fold_stats_kernel(const bf16_t* __restrict__ w, const double* __restrict__ gram, const double* __restrict__ sx,
+                                                         double* __restrict__ sums, int Cout, int Cin) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= Cout) return;
+  const bf16_t* wr = w + (long long)c * Cin;
+  double s = 0.0, q = 0.0;
+  for (int k = lane; k < Cin; k += 64) {
+    const double wk = (double)bf16_to_f32(wr[k]);
+    s += wk * sx[k];
+    double t = 0.0;
+    for (int j = 0; j < Cin; ++j) t += (double)bf16_to_f32(wr[j]) * gram[(long long)j * Cin + k];
+    q += wk * t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    sums[c] = s;
+    sums[Cout + c] = q;
+  }
+}
+
+extern "C" int maai_fold_stats(const void* w, const double* gram, const double* sx, double* sums, int Cout, int Cin, void* stream) {
+  MAAI_CHECK_ARG(w && gram && sx && sums && Cout > 0 && Cin > 0, "fold_stats: bad arguments");
+  hipLaunchKernelGGL(fold_stats_kernel, dim3((Cout + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)w, gram, sx, sums,
+                     Cout, Cin);
+  MAAI_CHECK_LAUNCH();
+  return MAAI_OK;
+}
+
 extern "C" int maai_fold_s2(const void* w, const float* g1, const double* s1, const float* mean, double* s2, int Cout, int Cin, void* stream) {
   MAAI_CHECK_ARG(w && g1 && s1 && mean && s2 && Cout > 0 && Cin > 0, "fold_s2: bad arguments");
   hipLaunchKernelGGL(fold_s2_kernel, dim3((Cout + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (const bf16_t*)w, g1, s1, mean, s2, Cout, Cin);

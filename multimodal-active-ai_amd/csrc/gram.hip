@@ -22,6 +22,8 @@ struct GramArgs {
   float* gram;   // [C][C], += (zeroed by the caller)
   double* sx;    // [C], += (zeroed by the caller)
   double* npos;  // [C], += the number of rows with x > 0 (nullable)
+  float* pgram;  // deterministic mode (nullable): partial Gram matrices [gridDim.x][C][C] written, not accumulated — and
+  float* psx;    //   partial column sums [gridDim.x][C]; summed by the caller in a fixed order (maai_reduce_partials)
   long long M;
   int ntiles;
 };
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = cls * CR + (widu * TR + r) * 16 + 4 * gl + e;
-        atomicAdd(a.gram + (long long)row * C + c * 16 + li, acc[r][c][e]);
+        if (a.pgram) a.pgram[((long long)blockIdx.x * C + row) * C + c * 16 + li] = acc[r][c][e];
+        else atomicAdd(a.gram + (long long)row * C + c * 16 + li, acc[r][c][e]);
       }
   if (cls == 0) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
     for (int c = tid; c < C; c += 256) {
       double s = 0.0;
       for (int k = 0; k < PSTEP; ++k) s += (double)red[k * C + c];
-      atomicAdd(a.sx + c, s);
+      if (a.psx) a.psx[(long long)blockIdx.x * C + c] = (float)s;
+      else atomicAdd(a.sx + c, s);
     }
     if (a.npos) {
       __syncthreads();
@@ -189,6 +193,40 @@ static int launch_gram(const GramArgs& a, hipStream_t st) {
   return MAAI_OK;
 }
 
+extern "C" int maai_gram_partial_rows(long long M, int C) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncls = C / (C < 128 ? C : 128);
+  long long gx = (long long)cus * (C <= 128 ? 2 : 1) / ncls;
+  const long long ntiles = (M + 63) / 64;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  return (int)gx;
+}
+
+// Deterministic form: partial Gram matrices pgram [maai_gram_partial_rows(M, C)][C][C] and partial column sums psx [rows][C]
+// (fp32, one row per workgroup column, every element written) — no atomics: the caller sums the rows in a fixed order
+// (maai_reduce_partials), so the result is bit-reproducible and may feed FORWARD statistics (maai_fold_stats).
+extern "C" int maai_gram_partials(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* pgram,
+                                  float* psx, void* stream) {
+  MAAI_CHECK_ARG(x && pgram && psx && M > 0 && (xs == nullptr) == (xt == nullptr), "gram_partials: bad arguments");
+  MAAI_CHECK_ARG(M < (1ll << 31), "gram_partials: pixel count must fit 31 bits");
+  GramArgs a;
+  a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = nullptr; a.sx = nullptr; a.npos = nullptr; a.pgram = pgram; a.psx = psx;
+  a.M = M; a.ntiles = (int)((M + 63) / 64);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  switch (C) {
+    case 64: return launch_gram<64>(a, st);
+    case 128: return launch_gram<128>(a, st);
+    case 256: return launch_gram<256>(a, st);
+    case 512: return launch_gram<512>(a, st);
+    default: break;
+  }
+  maai_set_error("gram: built for 64, 128, 256 and 512 channels");
+  return MAAI_ERR_UNSUPPORTED;
+}
+
 // x [M][C] bf16 (C = 64, 128, 256 or 512), optionally normalised on load (xs, xt [C], x_relu); gram [C][C] fp32, sx [C] fp64
 // and npos [C] fp64 (nullable: rows with x > 0 per channel) are ACCUMULATED into (zero them first).
 extern "C" int maai_gram(const void* x, long long M, int C, const float* xs, const float* xt, int x_relu, float* gram, double* sx,
@@ -196,7 +234,7 @@ extern "C" int maai_gram(const void* x, long long M, int C, const float* xs, con
   MAAI_CHECK_ARG(x && gram && sx && M > 0 && (xs == nullptr) == (xt == nullptr), "gram: bad arguments");
   MAAI_CHECK_ARG(M < (1ll << 31), "gram: pixel count must fit 31 bits");
   GramArgs a;
-  a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = gram; a.sx = sx; a.npos = npos; a.M = M; a.ntiles = (int)((M + 63) / 64);
+  a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = gram; a.sx = sx; a.npos = npos; a.pgram = nullptr; a.psx = nullptr; a.M = M; a.ntiles = (int)((M + 63) / 64);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
     case 64: return launch_gram<64>(a, st);

@@ -93,6 +93,9 @@ SIGNATURES = {
     "maai_fold_dw": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_fold_dgrad_w": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_gram": (c_i, [c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "maai_gram_partial_rows": (c_i, [c_ll, c_i]),
+    "maai_gram_partials": (c_i, [c_p, c_ll, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "maai_fold_stats": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "maai_conv_dfold_rows": (c_ll, [c_ll]),
     "maai_conv_dfold": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p]),
     "maai_comm_create": (c_i, [c_i, c_i, c_ll, c_p]),

@@ -217,7 +217,7 @@ def w_linear_dgrad(param, dtype, nhwc_from=None):
 # ----------------------------------------------------------------------------
 class _Rec(object):
     __slots__ = ("x", "y", "out", "conv", "bn", "k", "stride", "pad", "relu", "has_res", "mean", "invstd", "scale",
-                 "count", "world", "training", "form", "in_hw", "fused", "shift", "bits", "fold")
+                 "count", "world", "training", "form", "in_hw", "fused", "shift", "bits", "fold", "gram")
 
 
 # Pointwise expanding convolutions with few input channels (conv3 / downsample of the first stages) are HBM-bound
@@ -314,6 +314,14 @@ _LAZY = {"enabled": os.environ.get("MAAI_LAZY", "1") != "0", "join": os.environ.
 # join 4.1 ms -> statistics 0.73 + chained 3.5 ms).  With a backward pass y3 has to be stored and the chained launch
 # loses (6.3 vs 5.8 ms), so those forwards keep the two launches.  MAAI_CHAIN=0 turns it off.
 _CHAIN = {"enabled": os.environ.get("MAAI_CHAIN", "1") != "0"}
+# Statistics of a chained conv3 from Gram(x) and colsum(x) instead of a statistics-only launch (see _unit_fwd_gen; MAAI_GRAM_STATS=0:
+# the launch — whose slab is the one the unchained path sums, so that chained and unchained forwards agree bit for bit; with the
+# Gram form they agree to fp32 summation order, ~1e-6 in the statistics).
+_GRAMSTATS = {"enabled": os.environ.get("MAAI_GRAM_STATS", "1") != "0"}
+
+
+def set_gram_stats(flag):
+    _GRAMSTATS["enabled"] = bool(flag)
 
 
 def set_chain(enabled):
@@ -750,6 +758,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
             return (res[0], res[1]) if stats else res[0]
         return K.conv2d(x, wq, stride, pad, pad_w, stats=stats)
     y = None
+    gram_keep = None
     # chained block boundary: this convolution is not run here (training: only its statistics are taken) — the next block's
     # first convolution recomputes it inside the launch that joins it with the shortcut
     # (with gradients too where the unit's backward is folded: it reads neither the raw output nor recomputes it)
@@ -762,14 +771,24 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         mean, invstd, scale, shift, count, world = given.mean, given.invstd, given.scale, given.shift, given.count, given.world
     elif training:
         if fused or chain:
-            part = K.conv2d_stats_only(x, wq)
             c = wq.shape[0]
             count = x.numel() // x.shape[-1] if not isinstance(x, K.Lazy) else x.y.numel() // x.y.shape[-1]
+            if (chain and _GRAMSTATS["enabled"] and dtype == torch.bfloat16 and wq.shape[3] in K.GRAM_CHANNELS
+                    and not (isinstance(x, K.Lazy) and (x.b is not None or x.pre is not None))):
+                # the statistics of y = x W^T from Gram(x) and colsum(x) — sum y = W sx, sum y^2 = diag(W Gram W^T) — instead of a
+                # statistics-only launch that computes the whole convolution to throw it away (0.35 vs 0.78 ms at 224^2 x 256);
+                # deterministic (fixed-order partials).  The backward of the folded unit needs exactly these two: kept on the record.
+                g64, sx64 = K.gram_deterministic(x)
+                sums = K.fold_stats(wq, g64, sx64)
+                if keep and not light:
+                    gram_keep = (g64.float(), sx64)
+            else:
+                sums = K.reduce_partials(K.conv2d_stats_only(x, wq))
         else:
             y, part = conv_x(True)
             c = y.shape[-1]
             count = y.numel() // c
-        sums = K.reduce_partials(part)
+            sums = K.reduce_partials(part)
         world = _sync_world(bn)
         gathered = None
         if world > 1:
@@ -827,7 +846,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused, r.shift, r.bits, r.fold = (x.shape[1], x.shape[2]), True, shift, fbits, None
+        r.in_hw, r.fused, r.shift, r.bits, r.fold, r.gram = (x.shape[1], x.shape[2]), True, shift, fbits, None, None
         return out, r
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor
@@ -852,7 +871,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
         r.in_hw = (x.shape[1], x.shape[2])
-        r.fused, r.shift, r.bits, r.fold = False, shift, None, None
+        r.fused, r.shift, r.bits, r.fold, r.gram = False, shift, None, None, gram_keep
         return lz, r
     elif branch is not None:
         if residual is not None:
@@ -871,7 +890,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
     r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, (residual is not None or branch is not None)
     r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
     r.in_hw = (x.shape[1], x.shape[2])
-    r.fused, r.shift, r.bits, r.fold = False, shift, bits, None
+    r.fused, r.shift, r.bits, r.fold, r.gram = False, shift, bits, None, None
     return ((y, scale, shift) if defer else out), r
 
 
@@ -1204,7 +1223,9 @@ def _unit_bwd_folded(rec, g, grads, dtype, k1, k2, k3, need_dx, dx_out, accumula
     cout, cin = w.shape[0], w.shape[1]
     wq = w_fwd(w, dtype).reshape(cout, cin)
     x = rec.x
-    if cin in K.GRAM_CHANNELS:
+    if rec.gram is not None:
+        gram, sx = rec.gram                    # (the forward took its statistics from them: chained boundary, _GRAMSTATS)
+    elif cin in K.GRAM_CHANNELS:
         gram, sx = K.gram(x)                   # Gram = x^T x and colsum(x) in one pass over x (csrc/gram.hip)
     else:
         xm = materialise(x)
@@ -1301,7 +1322,7 @@ def set_recompute(flag, layers=None):
 
 def _lighten(r):
     if r is not None:
-        r.x = r.y = r.out = r.bits = r.fold = None
+        r.x = r.y = r.out = r.bits = r.fold = r.gram = None
     return r
 
 

@@ -861,6 +861,41 @@ def gram(x):
     return g, sx
 
 
+def gram_deterministic(x):
+    """(Gram = x^T x [C,C], sx = colsum(x) [C]) in fp64 from per-workgroup fp32 partials summed in a fixed order
+    (maai_gram_partials + maai_reduce_partials): bit-reproducible, so it may feed FORWARD statistics (``fold_stats``)."""
+    xs = xt = None
+    x_relu = 0
+    if isinstance(x, Lazy):
+        if x.b is not None or x.pre is not None:
+            raise MaaiError("gram: a tensor or a single-tensor Lazy")
+        _gpu(x.scale, x.shift)
+        xs, xt, x_relu, x = x.scale, x.shift, 1 if x.relu else 0, x.y
+    _gpu(x)
+    c = x.shape[-1]
+    if x.dtype != torch.bfloat16 or c not in GRAM_CHANNELS:
+        raise MaaiError("gram: bf16 activations with 64, 128, 256 or 512 channels")
+    m = x.numel() // c
+    rows = int(lib().maai_gram_partial_rows(m, c))
+    pg = torch.empty((rows, c * c), dtype=torch.float32, device=x.device)
+    ps = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    with _timed("gram" if not DETAIL[0] else "gram[det] M%d C%d" % (m, c), 2.0 * m * c * c, 2.0 * x.numel(), 0.0):
+        check(lib().maai_gram_partials(_p(x), m, c, _p(xs), _p(xt), x_relu, _p(pg), _p(ps), _stream()), "maai_gram_partials")
+    return reduce_partials(pg).reshape(c, c), reduce_partials(ps)
+
+
+def fold_stats(wq, gram64, sx64):
+    """fp64 [2*Cout] = sum y | sum y^2 of y = x W^T from Gram(x) and colsum(x) (``gram_deterministic``): what
+    ``reduce_partials`` of a statistics-only launch returns, without the launch."""
+    _gpu(wq, gram64, sx64)
+    cout, cin = wq.shape[0], wq.numel() // wq.shape[0]
+    if wq.dtype != torch.bfloat16 or gram64.dtype != torch.float64 or sx64.dtype != torch.float64 or gram64.numel() != cin * cin or sx64.numel() != cin:
+        raise MaaiError("fold_stats: bf16 weights [Cout,Cin], fp64 Gram [Cin,Cin] and column sums [Cin]")
+    sums = torch.empty(2 * cout, dtype=torch.float64, device=wq.device)
+    check(lib().maai_fold_stats(_p(wq), _p(gram64), _p(sx64), _p(sums), cout, cin, _stream()), "maai_fold_stats")
+    return sums
+
+
 def conv_dfold(g, y2, wcat, cn, mean2, s2, t2, dx=None, dg=None):
     """The folded 64 -> 256 unit's data gradient (csrc/conv_dfold.hip): dx = ([g | relu(bn2(y2))] Wcat^T + cn + dg*a2) * [a2 > 0] with
     the unit below's BatchNorm-backward partial sums -> (dx [.., 64], slab [rows, 2, 64]).  ``dx`` given: += in place."""

@@ -388,3 +388,30 @@ def test_folded_sums_below_over_seeds(E, record_property):
     print(msg)
     record_property("fold_sums_below", msg)
     assert ef[5] <= 3.0 * eu[5] + 2.0 ** -8 and ef[-1] <= 0.05, msg
+
+
+@pytest.mark.parametrize("m,cin,cout,xf", [(12544, 64, 256, True), (5000, 64, 256, False), (3136, 128, 512, True), (777, 256, 1024, False)])
+def test_statistics_from_gram_match_the_statistics_only_launch(E, m, cin, cout, xf):
+    """The BatchNorm statistics of y = x W^T without computing y (sum y = W sx, sum y^2 = diag(W Gram W^T); deterministic Gram
+    partials, csrc/gram.hip + fold_stats_kernel) — the chained block boundaries of layer 1 — against the statistics-only launch
+    they replace (fp32 summation order apart) and fp64; two runs give the same bits."""
+    from maai_hip import kernels as K
+    g = torch.Generator().manual_seed(m + cin)
+    y = torch.randn(1, 1, m, cin, generator=g).cuda().bfloat16()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda().bfloat16()
+    if xf:
+        x = K.Lazy(y, (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.5).cuda(), True)
+    else:
+        x = y
+    g64, sx64 = K.gram_deterministic(x)
+    sums = K.fold_stats(w, g64, sx64)
+    g64b, sx64b = K.gram_deterministic(x)
+    assert torch.equal(g64, g64b) and torch.equal(sx64, sx64b)
+    ref = K.reduce_partials(K.conv2d_stats_only(x, w))
+    xm = E.materialise(x).double().reshape(m, cin)
+    yy = xm @ w.double().reshape(cout, cin).t()
+    exact = torch.cat([yy.sum(0), (yy * yy).sum(0)])
+    assert (sums - exact).abs().max() <= 2e-6 * exact.abs().max()
+    assert (sums - ref).abs().max() <= 5e-6 * ref.abs().max()
+    ga, sa = K.gram(x)
+    assert (ga.double() - g64).abs().max() <= 1e-5 * g64.abs().max() and (sa - sx64).abs().max() <= 1e-5 * sx64.abs().max()
