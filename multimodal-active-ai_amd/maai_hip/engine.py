@@ -317,7 +317,11 @@ _CHAIN = {"enabled": os.environ.get("MAAI_CHAIN", "1") != "0"}
 # Statistics of a chained conv3 from Gram(x) and colsum(x) instead of a statistics-only launch (see _unit_fwd_gen; MAAI_GRAM_STATS=0:
 # the launch — whose slab is the one the unchained path sums, so that chained and unchained forwards agree bit for bit; with the
 # Gram form they agree to fp32 summation order, ~1e-6 in the statistics).
-_GRAMSTATS = {"enabled": os.environ.get("MAAI_GRAM_STATS", "1") != "0"}
+# MAAI_GRAM_STATS_FUSED=0: only the chained boundaries of layer 1, not the recompute-form units of stages 2-3.
+_GRAMSTATS = {"enabled": os.environ.get("MAAI_GRAM_STATS", "1") != "0", "fused": os.environ.get("MAAI_GRAM_STATS_FUSED", "1") != "0",
+              # below this many pixels a statistics-only launch costs nothing, and a batch variance over a handful of pixels can sit
+              # arbitrarily far below w^T Gram w / M, the scale the Gram form's fp32 rounding is relative to
+              "min_rows": int(os.environ.get("MAAI_GRAM_STATS_MIN_ROWS", "1024"))}
 
 
 def set_gram_stats(flag):
@@ -773,7 +777,8 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         if fused or chain:
             c = wq.shape[0]
             count = x.numel() // x.shape[-1] if not isinstance(x, K.Lazy) else x.y.numel() // x.y.shape[-1]
-            if (chain and _GRAMSTATS["enabled"] and dtype == torch.bfloat16 and wq.shape[3] in K.GRAM_CHANNELS
+            if (_GRAMSTATS["enabled"] and dtype == torch.bfloat16 and wq.shape[3] in K.GRAM_CHANNELS and (chain or _GRAMSTATS["fused"])
+                    and count >= _GRAMSTATS["min_rows"]
                     and not (isinstance(x, K.Lazy) and (x.b is not None or x.pre is not None))):
                 # the statistics of y = x W^T from Gram(x) and colsum(x) — sum y = W sx, sum y^2 = diag(W Gram W^T) — instead of a
                 # statistics-only launch that computes the whole convolution to throw it away (0.35 vs 0.78 ms at 224^2 x 256);
@@ -846,7 +851,7 @@ def _unit_fwd_gen(x, conv, bn, relu, residual, dtype, keep, wq=None, form="fwd",
         r.x, r.y, r.out, r.conv, r.bn = x, None, out, conv, bn
         r.k, r.stride, r.pad, r.relu, r.has_res = k, stride, pad, relu, residual is not None
         r.mean, r.invstd, r.scale, r.count, r.world, r.training, r.form = mean, invstd, scale, count, world, training, form
-        r.in_hw, r.fused, r.shift, r.bits, r.fold, r.gram = (x.shape[1], x.shape[2]), True, shift, fbits, None, None
+        r.in_hw, r.fused, r.shift, r.bits, r.fold, r.gram = (x.shape[1], x.shape[2]), True, shift, fbits, None, gram_keep
         return out, r
     # a residual unit's ReLU mask is kept as 1 bit per element for the backward pass (bf16): the data gradient that
     # flows into this output is masked from M*C/8 bytes instead of re-reading the output tensor

@@ -580,9 +580,9 @@ def _wgrad_target(d, x, dy, dtype_code):
     return best
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0, target_blocks=None):
     """dw[Cout,KH,KW,Cin] fp32 for y = conv(x, w); dy dense [N,OH,OW,Cout].  ``x`` may be a single-tensor ``Lazy``
-    activation (normalised on load)."""
+    activation (normalised on load).  ``target_blocks``: the split-K workgroup budget (default: measured per shape)."""
     xs = xt = None
     x_relu = 0
     if isinstance(x, Lazy):
@@ -594,7 +594,7 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad_h=0, pad_w=0):
     n, ih, iw, cin = x.shape
     _, oh, ow, cout = dy.shape
     d = ConvDesc(n, ih, iw, cin, cout, kh, kw, stride, pad_h, pad_w, oh, ow, oh, ow, 1, 0, 0, 0)
-    target = _wgrad_target(d, x, dy, _dt(x))
+    target = _wgrad_target(d, x, dy, _dt(x)) if target_blocks is None else int(target_blocks)
     dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=x.device)
     nm = "conv_wgrad" if not DETAIL[0] else "conv_wgrad M%d Cin%d Cout%d k%dx%d s%d" % (dy.numel() // cout, cin, cout, kh, kw, stride)
     with _timed(nm, 2.0 * dy.numel() * kh * kw * cin * FLOPS_SCALE[0], x.element_size() * (x.numel() + dy.numel()) + 4 * dw.numel()):

@@ -415,3 +415,49 @@ def test_statistics_from_gram_match_the_statistics_only_launch(E, m, cin, cout, 
     assert (sums - ref).abs().max() <= 5e-6 * ref.abs().max()
     ga, sa = K.gram(x)
     assert (ga.double() - g64).abs().max() <= 1e-5 * g64.abs().max() and (sa - sx64).abs().max() <= 1e-5 * sx64.abs().max()
+
+
+def test_gram_statistics_forward_is_close_to_the_launch_statistics(E):
+    """A ResNet-50 training forward with the statistics of the chained / recompute-form conv3 units taken from Gram(x)
+    (engine._GRAMSTATS) against the same forward with statistics-only launches: running statistics agree to 2e-4 of their scale where the inputs are identical, 2e-3 downstream (bf16 resolution: 4e-3),
+    the feature map to a few bf16 ulps of its scale (a statistic that moves by 1e-6 flips a rounding here and there, and the
+    flip travels on); and the Gram form is deterministic — two runs, the same bits."""
+    import sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = os.path.join(root, "multimodal-active-ai_amd/SimCLR/ResNet")
+    if p not in sys.path:
+        sys.path.append(p)
+    import copy
+    import resnet as rn
+    torch.manual_seed(11)
+    f0 = rn.resnet50(crop_measures=1).cuda()
+    for m in f0.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, rn.Bottleneck):
+            m.bn3.weight.data.mul_(0.25)
+    x = torch.randint(0, 256, (8, 3, 128, 128), device="cuda").float()   # (8192 / 2048 pixels in stages 1-2: Gram; 512 / 128 below min_rows)
+    res = []
+    try:
+        for gs in (True, True, False):
+            E.set_gram_stats(gs)
+            f = copy.deepcopy(f0).train()
+            with torch.no_grad():
+                o, _ = E.backbone_fwd(f, x, torch.bfloat16, keep=False)
+            res.append((o.float().clone(), {n: b.clone() for n, b in f.named_buffers()}))
+    finally:
+        E.set_gram_stats(True)
+    assert torch.equal(res[0][0], res[1][0])
+    for n, b in res[0][1].items():
+        assert torch.equal(res[1][1][n], b), n
+        if b.dtype.is_floating_point:
+            ref = res[2][1][n]
+            # the first unit with Gram statistics sees bit-identical inputs in both runs: var = w^T Gram w / M - mean^2 from
+            # fp32-accumulated Gram entries is relative to w^T Gram w (~1e3 x the variance after a ReLU); every later layer also
+            # sees an input with a few flipped bf16 roundings (2^-8 each)
+            tol = 2e-4 if n.startswith("layer1.0.bn3") else 2e-3
+            assert (b - ref).abs().max() <= tol * ref.abs().max() + 1e-6, n
+    a, b = res[0][0], res[2][0]
+    assert (a - b).abs().max() <= 2.0 ** -5 * b.abs().max()
+    assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.9999

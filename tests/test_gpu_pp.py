@@ -204,3 +204,49 @@ def test_pingpong_weight_gradient_matches_ring_kernels_and_fp64(K, case):
     F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wz, None, stride, pad).backward(dy.double().cpu().permute(0, 3, 1, 2))
     ref = wz.grad.permute(0, 2, 3, 1)
     np.testing.assert_allclose(d1.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
+
+
+WIDE_CASES = [
+    # N, H, W, Cin, Cout, PW
+    (4, 32, 32, 128, 128, 16),      # interior + border patches, one tile of dw
+    (4, 32, 32, 128, 128, 32),
+    (3, 28, 28, 512, 512, 32),      # the 512-channel layer's plane: 32-wide patches cover 87.5 %; 4 x 8 tiles of dw
+    (3, 28, 28, 256, 128, 16),      # ragged on both axes
+    (2, 56, 56, 256, 256, 16),      # the 256-channel layer's plane
+    (2, 19, 37, 64, 128, 32),       # odd extents, 64 input channels
+    (1, 5, 3, 64, 128, 16),         # a plane smaller than one patch
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wide_patch_weight_gradient_matches_patch_kernel_and_fp64(K, case):
+    """csrc/conv_wgrad3w.hip (eight waves, 128 x 9 x 64 blocks of dw, both patch geometries) against the kernels it replaces
+    (six-wave patch / ring, pinned to the oracle by test_gpu_kernels.py) and against fp64 autograd of conv2d
+    (resnet.py:20-23): same products, fp32 sums in a different order; and it is the kernel that ran."""
+    from maai_hip._lib import lib
+    n, h, w_, cin, cout, pw = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
+    dy = (torch.randn(n, h, w_, cout, generator=g) * 0.05).cuda().bfloat16()
+    K.AUTOTUNE[0] = False
+    were = lib().maai_kernel_names(1)
+    try:
+        with env(MAAI_WGRAD_WIDE="0", MAAI_WGRAD_PP="0"):
+            d0 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1)
+            assert b"wide" not in lib().maai_last_kernel_name()
+        with env(MAAI_WGRAD_WIDE="2", MAAI_WGRAD_WIDE_PW=str(pw)):
+            d1 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1)
+            assert b"wgrad3x3_wide_kernel<%d>" % pw in lib().maai_last_kernel_name()
+            d2 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1, target_blocks=3072)   # a different pixel split
+    finally:
+        K.AUTOTUNE[0] = True
+        lib().maai_kernel_names(were)
+    torch.cuda.synchronize()
+    scale = float(d0.abs().max())
+    assert d1.shape == d0.shape == (cout, 3, 3, cin)
+    assert float((d1 - d0).abs().max()) <= 2e-5 * scale + 1e-6, float((d1 - d0).abs().max() / scale)
+    assert float((d1 - d2).abs().max()) <= 2e-5 * scale + 1e-6      # (fp32 atomics: not bit-reproducible, documented)
+    wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wz, None, 1, 1).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    ref = wz.grad.permute(0, 2, 3, 1)
+    np.testing.assert_allclose(d1.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
