@@ -34,13 +34,16 @@ __device__ __forceinline__ void w3dma16(const void* gsrc, char* lds_dst) {
                : "memory");
 }
 
-template <int PW>
+// KS (layers with 64 output channels, or an odd multiple of 64): the block is 64(co) x 9 x 64(ci); wave (h, c) owns ALL four
+// output-channel tiles, input-channel tile c, all nine taps — of the K-steps {2h, 2h+1} of every patch (the two wave groups
+// split the pixels of a patch and both add their sums at the end).  Same 36 accumulator tiles, same 26 reads per 36 MFMAs.
+template <int PW, bool KS>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
   constexpr int TH = 128 / PW, HWS = PW + 8, RB = 128;   // patch rows, halo slots per row, bytes per pixel row (64 channels)
   constexpr int YI = 128 * RB;                           // one dY image (16 KB)
-  constexpr int YB = 2 * YI, HB = (TH + 2) * HWS * RB;   // dY bytes (32 KB), halo bytes (30 KB)
-  constexpr int NIY = YB / 1024, NIH = HB / 1024;        // wave-wide DMA instructions: 32 + 30
-  constexpr int PB = YB + HB;                            // one patch buffer (62 KB)
+  constexpr int YB = (KS ? 1 : 2) * YI, HB = (TH + 2) * HWS * RB;   // dY bytes (32 KB; KS: 16 KB), halo bytes (30 KB)
+  constexpr int NIY = YB / 1024, NIH = HB / 1024;        // wave-wide DMA instructions: 32 (KS: 16) + 30
+  constexpr int PB = YB + HB;                            // one patch buffer (62 KB; KS: 46 KB)
   constexpr int NDI = (NIY + NIH + 7) / 8;
   constexpr int ROWSTEP = PW == 16 ? 2 : 1;              // halo rows per K-step
   constexpr int HI_OFF = PW == 16 ? HWS * RB : 16 * RB;  // where the second 16 pixels of a K-step sit relative to the first
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
   const int ntiles = a.nCoB * a.nCiB;
   const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
   const int cob = tile / a.nCiB, cib = tile - cob * a.nCiB;
-  const int co0 = cob * 128, ci0 = cib * 64;
+  const int co0 = cob * (KS ? 64 : 128), ci0 = cib * 64;
   const bf16_t* __restrict__ x = reinterpret_cast<const bf16_t*>(a.x);
   const bf16_t* __restrict__ dy = reinterpret_cast<const bf16_t*>(a.dy);
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_3wzero);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = 2 * i + (p >> 1);
-    offA[i] = half * YI + r0 * RB + ((c ^ (((r0 >> 1) & 3) << 1)) << 4) + ((p & 1) << 3);
+    offA[i] = (KS ? 0 : half * YI) + r0 * RB + ((c ^ (((r0 >> 1) & 3) << 1)) << 4) + ((p & 1) << 3);
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();   // patch pt is complete in LDS; everyone is done multiplying patch pt-1
     if (pt + 1 < p_end) issue_patch(pt + 1, smem + (int)((pt + 1 - p_begin) & 1) * PB);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[4];
+    // software pipeline (MAAI_W3_PIPE): the halo fragments of the next kernel row (or of the next K-step's first row) are read
+    // under the MFMAs of the current one; the dY fragments of the next K-step behind its last MFMA group
+    auto load_a = [&](int s, bf16x8* af) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const char* base = buf + s * 32 * RB + offA[i];
@@ -164,21 +167,52 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(base + 16 * RB));
         af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
+    };
+    auto load_b = [&](int s, int kh, bf16x8* bfr) {
+      const char* hrow = buf + (ROWSTEP * s + kh) * (HWS * RB);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(hrow + offB[k]));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(hrow + HI_OFF + offB[k]));
+        bfr[k] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    };
+    bf16x8 af[4], bcur[3], bnxt[3];
+    constexpr int NS = KS ? 2 : 4;
+    const int s0 = KS ? 2 * half : 0;
+    load_a(s0, af);
+    load_b(s0, 0, bcur);
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+      const int s = s0 + ss;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const char* hrow = buf + (ROWSTEP * s + kh) * (HWS * RB);
-        bf16x8 bfr[3];
+        const bool more = kh < 2 || ss < NS - 1, next_a = kh == 2 && ss < NS - 1;
+        if (kh < 2) load_b(s, kh + 1, bnxt);
+        else if (ss < NS - 1) load_b(s + 1, 0, bnxt);
+        // i-major: a dY fragment is done after three MFMAs and its successor (next K-step) is read right behind them — it is
+        // needed again nine MFMAs later
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(hrow + offB[k]));
-          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(hrow + HI_OFF + offB[k]));
-          bfr[k] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[i][kh][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bcur[k], acc[i][kh][k], 0, 0, 0);
+          if (next_a) {
+            const char* base = buf + (s + 1) * 32 * RB + offA[i];
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(base));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_3w*)(base + 16 * RB));
+            af[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
         }
+        // the order the scheduler must keep: this region's halo reads first, then MFMAs (with the dY reads between them)
+        if (more) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          if (next_a) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (register budget: nothing is hoisted across kernel rows)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][kh][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[k], acc[i][kh][k], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);   // keep the next kernel row's fragment reads from being hoisted (register budget)
+        for (int k = 0; k < 3; ++k) bcur[k] = bnxt[k];
       }
     }
   }
@@ -191,7 +225,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
       for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = co0 + half * 64 + i * 16 + 4 * g + r;
+          const int co = co0 + (KS ? 0 : half * 64) + i * 16 + 4 * g + r;
           const int ci = ci0 + ct * 16 + li;
           atomicAdd(a.dw + (((long long)co * 3 + kh) * 3 + k) * a.Cin + ci, acc[i][kh][k][r]);
         }
@@ -206,13 +240,13 @@ static void w3_geometry(const Wgrad3wArgs& a, int pw, int* tx, int* ty, double* 
 
 // MAAI_WGRAD_WIDE = 0 | 1 (shape rule, default) | 2 (every shape it is built for), read per call
 bool maai_wgrad3w_supported(const Wgrad3wArgs& a, bool* by_rule) {
-  if (!(a.Cin % 64 == 0 && a.Cout % 128 == 0 && a.H >= 3 && a.W >= 3)) return false;
+  if (!(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.H >= 3 && a.W >= 3)) return false;
   int tx, ty;
   double c16, c32;
   w3_geometry(a, 16, &tx, &ty, &c16);
   w3_geometry(a, 32, &tx, &ty, &c32);
   const double cover = c16 > c32 ? c16 : c32;
-  *by_rule = cover >= 0.85 && (long long)a.N * a.H * a.W >= 65536 && a.Cin >= 128;
+  *by_rule = cover >= 0.85 && (long long)a.N * a.H * a.W >= 65536;
   return true;
 }
 
@@ -226,7 +260,8 @@ int maai_wgrad3w_launch(Wgrad3wArgs a, hipStream_t st, int target) {
   if (e && (atoi(e) == 16 || atoi(e) == 32)) pw = atoi(e);
   a.tilesX = pw == 16 ? tx16 : tx32;
   a.tilesY = pw == 16 ? ty16 : ty32;
-  a.nCoB = a.Cout / 128;
+  const bool ks = a.Cout % 128 != 0;
+  a.nCoB = a.Cout / (ks ? 64 : 128);
   a.nCiB = a.Cin / 64;
   a.npatch = (long long)a.N * a.tilesX * a.tilesY;
   const long long tiles = (long long)a.nCoB * a.nCiB;
@@ -236,18 +271,20 @@ int maai_wgrad3w_launch(Wgrad3wArgs a, hipStream_t st, int target) {
   if (split < 1) split = 1;
   a.per_split = (a.npatch + split - 1) / split;
   split = (a.npatch + a.per_split - 1) / a.per_split;
-  constexpr int lds = 2 * (2 * 128 * 128 + 240 * 128);   // two 62 KB patch buffers
-  static int attr[2][64] = {{0}};
+  const int lds = 2 * ((ks ? 1 : 2) * 128 * 128 + 240 * 128);   // two patch buffers of 62 KB (KS: 46 KB)
+  static int attr[4][64] = {{0}};
   const dim3 grid((unsigned)(tiles * split));
-  if (pw == 16) {
-    maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_wide_kernel<16>), lds, attr[0]);
-    MAAI_NOTE_KERNEL(wgrad3x3_wide_kernel<16>);
-    hipLaunchKernelGGL((wgrad3x3_wide_kernel<16>), grid, dim3(512), lds, st, a);
-  } else {
-    maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_wide_kernel<32>), lds, attr[1]);
-    MAAI_NOTE_KERNEL(wgrad3x3_wide_kernel<32>);
-    hipLaunchKernelGGL((wgrad3x3_wide_kernel<32>), grid, dim3(512), lds, st, a);
-  }
+#define MAAI_W3_LAUNCH(PW_, KS_, slot)                                                                     \
+  do {                                                                                                     \
+    maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_wide_kernel<PW_, KS_>), lds, attr[slot]);       \
+    MAAI_NOTE_KERNEL(wgrad3x3_wide_kernel<PW_, KS_>);                                                      \
+    hipLaunchKernelGGL((wgrad3x3_wide_kernel<PW_, KS_>), grid, dim3(512), lds, st, a);                     \
+  } while (0)
+  if (pw == 16 && !ks) MAAI_W3_LAUNCH(16, false, 0);
+  else if (pw == 16) MAAI_W3_LAUNCH(16, true, 1);
+  else if (!ks) MAAI_W3_LAUNCH(32, false, 2);
+  else MAAI_W3_LAUNCH(32, true, 3);
+#undef MAAI_W3_LAUNCH
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;
 }

@@ -6,7 +6,7 @@ import torch
 from maai_hip import kernels as K
 from maai_hip._lib import lib
 
-SHAPES = [(256, 56, 56, 256, 256), (256, 28, 28, 512, 512), (256, 112, 112, 128, 128), (64, 224, 224, 64, 128)]
+SHAPES = [(256, 56, 56, 256, 256), (256, 28, 28, 512, 512), (256, 112, 112, 128, 128), (256, 224, 224, 64, 64)]
 CONFIGS = [("patch", dict(MAAI_WGRAD_WIDE="0", MAAI_WGRAD_PP="0")), ("pingpong", dict(MAAI_WGRAD_WIDE="0", MAAI_WGRAD_PP="2")),
            ("wide16", dict(MAAI_WGRAD_WIDE="2", MAAI_WGRAD_WIDE_PW="16")), ("wide32", dict(MAAI_WGRAD_WIDE="2", MAAI_WGRAD_WIDE_PW="32"))]
 TARGETS = [0, 256, 512, 768, 1536, 3072]

@@ -215,6 +215,11 @@ WIDE_CASES = [
     (2, 56, 56, 256, 256, 16),      # the 256-channel layer's plane
     (2, 19, 37, 64, 128, 32),       # odd extents, 64 input channels
     (1, 5, 3, 64, 128, 16),         # a plane smaller than one patch
+    # 64 output channels (or an odd multiple): the K-split form — the two wave groups share a patch's pixels
+    (2, 32, 32, 64, 64, 16),
+    (2, 30, 33, 64, 64, 32),
+    (2, 19, 37, 128, 192, 32),
+    (1, 5, 3, 64, 64, 16),
 ]
 
 
@@ -236,7 +241,7 @@ def test_wide_patch_weight_gradient_matches_patch_kernel_and_fp64(K, case):
             assert b"wide" not in lib().maai_last_kernel_name()
         with env(MAAI_WGRAD_WIDE="2", MAAI_WGRAD_WIDE_PW=str(pw)):
             d1 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1)
-            assert b"wgrad3x3_wide_kernel<%d>" % pw in lib().maai_last_kernel_name()
+            assert b"wgrad3x3_wide_kernel<%d, %s>" % (pw, b"true" if cout % 128 else b"false") in lib().maai_last_kernel_name()
             d2 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1, target_blocks=3072)   # a different pixel split
     finally:
         K.AUTOTUNE[0] = True
