@@ -17,11 +17,12 @@ Workload: ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224,
 bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,1024,128),
 temperature 0.5.  N = 1, 2, 4: BASELINE configs[1] per GPU (per-GPU batch 256,
 weak scaling).  N = 8: BASELINE configs[2] = the metric's own configuration,
-per-GPU batch 512 (global 4096) with block recompute of stages 1-2 (512 images
-of stored activations do not fit 288 GB); the program is fixed by the flags —
+per-GPU batch 512 (global 4096) with block recompute of stage 1 and lean
+activations (512 images of stored activations do not fit 288 GB: 242 GB
+allocated / 264 GB reserved this way); the program is fixed by the flags —
 never by a free-memory probe — so every rank and every run executes the same
-launches (MAAI_RECOMPUTE_LAYERS=1,2,3 names other stages); --batch /
---recompute / --no-recompute override.
+launches (MAAI_RECOMPUTE_LAYERS=1,2 names other stages: -40 GB, -5 %);
+--batch / --recompute / --no-recompute override.
 Synthetic images are per-image random low-frequency colour patterns plus
 noise, generated on the device, so that the two views of one image correlate
 and the contrastive loss is NOT the 2*ln(2N-1) of collapsed embeddings; the
@@ -295,10 +296,11 @@ def main():
     rc_layers = None
     if args.recompute:
         from maai_hip import engine
-        # Which stages are recomputed is part of the command, not of the machine's state: stages 1-2 (they hold ~80 % of
-        # the activation bytes; layers 3-4 stay stored and are not run a second time) unless MAAI_RECOMPUTE_LAYERS says
-        # otherwise.  Every rank of every run executes the same program.
-        rc_layers = sorted(engine._RECOMPUTE["layers"]) if os.environ.get("MAAI_RECOMPUTE_LAYERS") else [1, 2]
+        # Which stages are recomputed is part of the command, not of the machine's state: stage 1 (it holds ~half of the
+        # activation bytes; with lean activations — on together with recompute, engine._LEAN — 512 images then take 242 GB
+        # allocated / 264 GB reserved, measured; stages 2-4 stay stored and are not run a second time) unless
+        # MAAI_RECOMPUTE_LAYERS says otherwise (1,2: 201 / 231 GB, 5 % slower).  Every rank of every run executes the same program.
+        rc_layers = sorted(engine._RECOMPUTE["layers"]) if os.environ.get("MAAI_RECOMPUTE_LAYERS") else [1]
         engine.set_recompute(True, rc_layers)
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
@@ -324,7 +326,7 @@ def main():
         dt = time.perf_counter() - t0
     except torch.cuda.OutOfMemoryError as e:
         # the program is fixed by the flags (no free-memory probe picks another one behind the user's back): say which flag helps
-        hint = ("MAAI_RECOMPUTE_LAYERS=1,2,3 recomputes stage 3 as well (-~60 GB at 512 images)" if args.recompute
+        hint = ("MAAI_RECOMPUTE_LAYERS=1,2 recomputes stage 2 as well (-~40 GB at 512 images), 1,2,3 stage 3 too" if args.recompute
                 else "--recompute rebuilds the blocks of stages 1-2 in the backward instead of storing their activations")
         raise SystemExit("bench.py: out of HBM at --batch %d (recompute %s): %s\n%s" % (args.batch, rc_layers if args.recompute else "off", hint, e))
     losses = [float(v.item()) for v in losses]
@@ -437,7 +439,7 @@ def main():
                                    % (args.arch, args.img, args.img, args.batch, " with block recompute" if args.recompute else "",
                                       args.temperature, "configs[2] (global batch 4096)" if world * args.batch == 4096 else "configs[1] per GPU"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": losses[-1], "loss_first_timed_step": losses[0],
-                       "recompute": bool(args.recompute), "recompute_layers": rc_layers, "overlap_views": bool(overlap), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                       "recompute": bool(args.recompute), "recompute_layers": rc_layers, "overlap_views": bool(overlap), "lean_activations": bool(_engine._lean()), "hbm_total_GB": round(torch.cuda.mem_get_info()[1] / 1e9, 1), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                        "peak_hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -1186,20 +1186,24 @@ def unit_bwd(rec, dout, grads, dtype, need_dx=True, dx_out=None, accumulate=Fals
         kh = 7 if rec.form == "stem_unrolled" else rec.k
         kw = 1 if rec.form == "stem_unrolled" else rec.k
         pw = 0 if rec.form == "stem_unrolled" else rec.pad
+        xw = rec.x
+        if isinstance(xw, K.Lazy) and rec.k == 3 and xw.b is None and xw.pre is None and _lean():
+            xw = materialise(xw)   # lean activations: one BatchNorm pass instead of a stored tensor (the 3x3 kernels want a tensor)
         if _SIDE["enabled"] and not K.DETAIL[0]:
             side, cur = _side_stream(), torch.cuda.current_stream()
             side.wait_stream(cur)                      # dy (and x) are ready on the main stream
             with torch.cuda.stream(side):
-                dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
+                dw = K.conv2d_wgrad(xw, dy, kh, kw, rec.stride, rec.pad, pw)
                 grads[id(w)] = _grad_to_reference(rec, dw)
             dy.record_stream(side)                     # keep the allocator from recycling them early
-            for t in ((rec.x.y, rec.x.b) if isinstance(rec.x, K.Lazy) else (rec.x,)):
+            for t in ((xw.y, xw.b) if isinstance(xw, K.Lazy) else (xw,)):
                 if t is not None:
                     t.record_stream(side)
             grads["_side"] = True
         else:
-            dw = K.conv2d_wgrad(rec.x, dy, kh, kw, rec.stride, rec.pad, pw)
+            dw = K.conv2d_wgrad(xw, dy, kh, kw, rec.stride, rec.pad, pw)
             grads[id(w)] = _grad_to_reference(rec, dw)
+        del xw
     if not fused_apply:
         dx, below_sums = None, None
     if need_dx:
@@ -1318,6 +1322,23 @@ _RECOMPUTE = {"enabled": os.environ.get("MAAI_RECOMPUTE", "0") == "1",
               "layers": frozenset(int(v) for v in os.environ.get("MAAI_RECOMPUTE_LAYERS", "1,2").split(",") if v.strip())}
 
 
+# Lean activations (memory): the normalised input of a bottleneck's 3x3 convolution, a1 = relu(bn1(y1)), is dropped after the
+# forward launch that reads it; the backward forms it again with one BatchNorm pass (same kernel, same operands: bit-identical)
+# right before the weight gradient.  y1 is stored anyway (bn1's backward reads it).  -23 GB of 141 at 256 images for ~1.5 % of
+# the step: "auto" (default) = only together with block recompute, i.e. when memory is what binds (512 images per GPU);
+# MAAI_LEAN_ACT=1 always, 0 never.
+_LEAN = {"mode": os.environ.get("MAAI_LEAN_ACT", "auto")}
+
+
+def set_lean_activations(mode):
+    """"auto" | True | False (see _LEAN)."""
+    _LEAN["mode"] = "auto" if mode == "auto" else ("1" if mode else "0")
+
+
+def _lean():
+    return _LEAN["mode"] == "1" or (_LEAN["mode"] == "auto" and _RECOMPUTE["enabled"])
+
+
 def set_recompute(flag, layers=None):
     """Block recompute on / off; ``layers``: the stages (1-4) whose blocks are recomputed (default: as configured)."""
     _RECOMPUTE["enabled"] = bool(flag)
@@ -1367,7 +1388,13 @@ def _block_fwd(blk, xin, dtype, keep, given=None, lazy_out=False, pol_keep=None)
     if isinstance(xin, K.Lazy) and xin.b is not None:
         xin = side["joined"]     # conv1 formed the join and handed it back
     if _is_bottleneck(blk):
+        a1 = o
         o, r2 = unit_fwd(o, blk.conv2, blk.bn2, True, None, dtype, keep, given=g2, lazy_out=_lazy_pays([blk.conv3], pol_keep))
+        if (keep and pol_keep and given is None and r1 is not None and r2 is not None and _lean() and r2.k == 3 and r1.out is not None
+                and r2.x is r1.out and a1 is r1.out and r1.y is not None and r1.relu and not r1.has_res and not r1.fused):
+            r2.x = K.Lazy(r1.y, r1.scale, r1.shift, True)   # (the backward re-forms a1 from y1: unit_bwd)
+            r1.out = None
+        del a1
         last_conv, last_bn = blk.conv3, blk.bn3
     else:  # BasicBlock
         r2 = None

@@ -14,7 +14,8 @@ timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-
 MAAI_FOLD=0 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap > $OUT/bench_b256_no_fold_no_overlap.json 2>/dev/null; echo "bench no-fold rc=$?" | tee -a $OUT/summary.txt
 timeout -k 10 400 python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --detail --profile-table $OUT/table.json > $OUT/bench_detail.json 2> $OUT/bench_detail.err; echo "bench detail rc=$?" | tee -a $OUT/summary.txt
 timeout -k 10 400 python3 bench.py --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_b512_recompute.json 2> $OUT/bench_b512.err; echo "bench512 rc=$?" | tee -a $OUT/summary.txt
-MAAI_RECOMPUTE_LAYERS=1 timeout -k 10 400 python3 bench.py --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_b512_recompute_stage1.json 2> $OUT/bench_b512_s1.err; echo "bench512 stage1 rc=$?" | tee -a $OUT/summary.txt
+MAAI_RECOMPUTE_LAYERS=1,2 timeout -k 10 400 python3 bench.py --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_b512_recompute_stage12.json 2> $OUT/bench_b512_s12.err; echo "bench512 stages 1-2 rc=$?" | tee -a $OUT/summary.txt
+MAAI_RECOMPUTE_LAYERS=1 MAAI_LEAN_ACT=0 timeout -k 10 400 python3 bench.py --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_b512_recompute_stage1_stored.json 2> $OUT/bench_b512_s1s.err; echo "bench512 stage 1, a1 stored rc=$?" | tee -a $OUT/summary.txt
 timeout -k 10 200 python3 scripts/eval_bench.py > $OUT/eval_bench.txt 2>&1; echo "eval bench rc=$?" | tee -a $OUT/summary.txt
-for f in $OUT/bench_b256.json $OUT/bench_b256_no_overlap.json $OUT/bench_b256_no_fold_no_overlap.json $OUT/bench_b512_recompute.json $OUT/bench_b512_recompute_stage1.json; do python3 -c "import json,sys;d=json.load(open('$f'));print('$f',d['value'],d['ms_per_step'],d['config']['peak_hbm_GB'],d['config'].get('overlap_views'))"; done
+for f in $OUT/bench_b256.json $OUT/bench_b256_no_overlap.json $OUT/bench_b256_no_fold_no_overlap.json $OUT/bench_b512_recompute.json $OUT/bench_b512_recompute_stage12.json $OUT/bench_b512_recompute_stage1_stored.json; do python3 -c "import json,sys;d=json.load(open('$f'));print('$f',d['value'],d['ms_per_step'],d['config']['peak_hbm_GB'],d['config'].get('overlap_views'))"; done
 tail -3 $OUT/eval_bench.txt
