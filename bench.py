@@ -17,12 +17,13 @@ Workload: ResNet-50 (reference stem: 7x7 stride 1, no max-pool), 3x224x224,
 bf16 storage / fp32 MFMA accumulate, 4x4 adaptive pool + MLP(32768,1024,128),
 temperature 0.5.  N = 1, 2, 4: BASELINE configs[1] per GPU (per-GPU batch 256,
 weak scaling).  N = 8: BASELINE configs[2] = the metric's own configuration,
-per-GPU batch 512 (global 4096) with block recompute of stage 1 and lean
-activations (512 images of stored activations do not fit 288 GB: 242 GB
-allocated / 264 GB reserved this way); the program is fixed by the flags —
-never by a free-memory probe — so every rank and every run executes the same
-launches (MAAI_RECOMPUTE_LAYERS=1,2 names other stages: -40 GB, -5 %);
---batch / --recompute / --no-recompute override.
+per-GPU batch 512 (global 4096) with lean activations (the 3x3 convolutions'
+normalised inputs are re-formed in the backward instead of stored: 250 GB
+allocated / 270 GB reserved of the 309 GB the device reports) and the two
+forwards one after the other; the program is fixed by the flags — never by a
+free-memory probe — so every rank and every run executes the same launches
+(--recompute: block recompute of stage 1 on top, 242 / 264 GB, -6 %;
+MAAI_RECOMPUTE_LAYERS=1,2: 201 / 231 GB, -11 %); --batch / --recompute override.
 Synthetic images are per-image random low-frequency colour patterns plus
 noise, generated on the device, so that the two views of one image correlate
 and the contrastive loss is NOT the 2*ln(2N-1) of collapsed embeddings; the
@@ -81,7 +82,7 @@ def parse():
     ap.add_argument("--profile-table", default="", help="write the per-kernel table (JSON) here")
     ap.add_argument("--detail", action="store_true", help="per-shape conv rows in the profile table")
     ap.add_argument("--recompute", action="store_true",
-                    help="block recompute in the backward (fits --batch 512 = global 4096 on 8 GPUs in 288 GB; one extra forward)")
+                    help="block recompute in the backward (stage 1 unless MAAI_RECOMPUTE_LAYERS names others): less memory, one extra forward of those stages")
     ap.add_argument("--no-recompute", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the two forwards of a step one after the other (default at N = 1 without recompute: the no-grad view on a side "
@@ -93,9 +94,11 @@ def parse():
         ap.error("--gpus must be >= 1")
     if args.batch <= 0:
         args.batch = 512 if args.gpus >= 8 else 256
-    # 512 images per GPU at 224 px do not fit without block recompute: on by default from there on
-    if args.batch * (args.img / 224.0) ** 2 >= 512 and not args.no_recompute:
-        args.recompute = True
+    # 512 images per GPU at 224 px: the stored activations fit the device (309 GB) only as "lean" ones — the 3x3 convolutions'
+    # normalised inputs re-formed in the backward (engine._LEAN) — and with the two forwards one after the other (the side stream's
+    # pool would come on top): 250 GB allocated / 270 GB reserved, measured.  --recompute trades 6 % for another 8 GB (stage 1
+    # rebuilt in the backward: 242 / 264 GB; MAAI_RECOMPUTE_LAYERS=1,2: 201 / 231 GB).
+    args.lean = bool(args.batch * (args.img / 224.0) ** 2 >= 512)
     return args
 
 
@@ -305,7 +308,9 @@ def main():
     model, opt = build(args, device, world)
     step = make_step(args, model, opt, device, rank, world)
     from maai_hip import engine as _engine
-    overlap = world == 1 and not args.recompute and not args.no_overlap and os.environ.get("MAAI_OVERLAP_VIEWS", "1") != "0"
+    if args.lean and os.environ.get("MAAI_LEAN_ACT", "auto") == "auto":
+        _engine.set_lean_activations(True)
+    overlap = world == 1 and not args.recompute and not args.lean and not args.no_overlap and os.environ.get("MAAI_OVERLAP_VIEWS", "1") != "0"
     _engine.set_overlap_views(overlap)
 
     def barrier():
@@ -327,7 +332,8 @@ def main():
     except torch.cuda.OutOfMemoryError as e:
         # the program is fixed by the flags (no free-memory probe picks another one behind the user's back): say which flag helps
         hint = ("MAAI_RECOMPUTE_LAYERS=1,2 recomputes stage 2 as well (-~40 GB at 512 images), 1,2,3 stage 3 too" if args.recompute
-                else "--recompute rebuilds the blocks of stages 1-2 in the backward instead of storing their activations")
+                else "--recompute rebuilds the blocks of stage 1 in the backward instead of storing their activations (-8 GB at 512 images; "
+                     "MAAI_RECOMPUTE_LAYERS=1,2 with it: -49 GB)")
         raise SystemExit("bench.py: out of HBM at --batch %d (recompute %s): %s\n%s" % (args.batch, rc_layers if args.recompute else "off", hint, e))
     losses = [float(v.item()) for v in losses]
     if not all(v == v and abs(v) < 1e30 for v in losses):
@@ -436,7 +442,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SimCLR %s 3x%dx%d (reference stem), per-GPU batch %d%s, two-view step: aug + fwd(view1, no grad) + "
                                    "fwd(view2) + NT-Xent tau=%g + bwd + Adam; BASELINE %s"
-                                   % (args.arch, args.img, args.img, args.batch, " with block recompute" if args.recompute else "",
+                                   % (args.arch, args.img, args.img, args.batch, (" with block recompute" if args.recompute else "") + (", lean activations" if _engine._lean() else ""),
                                       args.temperature, "configs[2] (global batch 4096)" if world * args.batch == 4096 else "configs[1] per GPU"),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": losses[-1], "loss_first_timed_step": losses[0],
                        "recompute": bool(args.recompute), "recompute_layers": rc_layers, "overlap_views": bool(overlap), "lean_activations": bool(_engine._lean()), "hbm_total_GB": round(torch.cuda.mem_get_info()[1] / 1e9, 1), "peak_hbm_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),

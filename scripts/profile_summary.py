@@ -23,7 +23,7 @@ def short(name):
     return name
 
 
-FAMILIES = (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("conv_chain_kernel", "conv_igemm"), ("conv_bwd3_kernel", "conv_igemm"), ("conv_pp_kernel", "conv_igemm"), ("conv_c64_kernel", "conv_igemm"), ("conv_dfold_kernel", "conv_igemm"), ("gram_kernel", "gram"), ("wgrad_pp_kernel", "conv_wgrad"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
+FAMILIES = (("conv_igemm_kernel", "conv_igemm"), ("conv_pws_kernel", "conv_igemm"), ("conv_chain_kernel", "conv_igemm"), ("conv_bwd3_kernel", "conv_igemm"), ("conv_pp_kernel", "conv_igemm"), ("conv_c64_kernel", "conv_igemm"), ("conv_dfold_kernel", "conv_igemm"), ("gram_kernel", "gram"), ("wgrad_pp_kernel", "conv_wgrad"), ("wgrad3x3_patch_kernel", "conv_wgrad"), ("wgrad3x3_wide_kernel", "conv_wgrad"), ("wgrad_ring_kernel", "conv_wgrad"), ("wgrad_kernel", "conv_wgrad"),
                  ("bn_act_fwd2_kernel", "bn_act_fwd"), ("bn_act_fwd_kernel", "bn_act_fwd"), ("bn_bwd_apply2_kernel", "bn_bwd_apply"),
                  ("bn_bwd_apply_kernel", "bn_bwd_apply"), ("bn_bwd_reduce_kernel", "bn_bwd_reduce"),
                  ("reduce_partials_kernel", "reduce_partials"))

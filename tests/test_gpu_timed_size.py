@@ -339,11 +339,11 @@ def test_fused_conv3_backward_at_256_images(K, acc):
 
 
 def test_recompute_step_at_512_images_per_gpu():
-    """BASELINE configs[2] per GPU: ResNet-50, 224 px, 512 images, block recompute.  One view-2 forward + NT-Xent + backward
-    with stages 1-2 recomputed (what bench.py --gpus 8 runs) and with every stage recomputed: the loss is bit-identical
-    (the forward is the same launches) and the gradients agree (a stored block's BatchNorm-backward sums ride the epilogue
-    above it; a recomputed one's do not: fp32 summation order).  Needs ~260 GB of free HBM: skipped when another tenant
-    holds memory."""
+    """BASELINE configs[2] per GPU: ResNet-50, 224 px, 512 images.  One view-2 forward + NT-Xent + backward with every stage
+    recomputed, with stages 1-2 recomputed, and with NOTHING recomputed but lean activations (engine._LEAN — what bench.py
+    --gpus 8 runs): the loss is bit-identical (the forward is the same launches) and the gradients agree (a stored block's
+    BatchNorm-backward sums ride the epilogue above it; a recomputed one's do not: fp32 summation order).  Needs ~270 GB of free
+    HBM: skipped when another tenant holds memory."""
     import gc
     import os
     import sys
@@ -360,8 +360,8 @@ def test_recompute_step_at_512_images_per_gpu():
     gc.collect()
     torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info()
-    if free < 266e9:
-        pytest.skip("needs ~260 GB of free HBM (free: %.0f GB)" % (free / 1e9))
+    if free < 280e9:
+        pytest.skip("needs ~270 GB of free HBM (free: %.0f GB)" % (free / 1e9))
     engine.set_precision("bf16")
     B, IMG = 512, 224
     torch.manual_seed(1234)
@@ -379,9 +379,10 @@ def test_recompute_step_at_512_images_per_gpu():
              "f.layer4.2.conv3.weight", "g.layers.0.weight", "g.layers.2.bias"]
     res = {}
     try:
-        for layers in ((1, 2, 3, 4), (1, 2)):
+        for layers in ((1, 2, 3, 4), (1, 2), ()):
             model.load_state_dict(sd0, strict=True)   # (running statistics as at the start)
-            engine.set_recompute(True, layers)
+            engine.set_recompute(bool(layers), layers or (1, 2))
+            engine.set_lean_activations(True)
             torch.cuda.reset_peak_memory_stats()
             h2 = model([v2])
             loss, _, _ = Objective.contrastive_loss(hidden1=h1, hidden2=h2, temperature=0.5, device="cuda")
@@ -396,11 +397,17 @@ def test_recompute_step_at_512_images_per_gpu():
             torch.cuda.empty_cache()
     finally:
         engine.set_recompute(False, (1, 2))
+        engine.set_lean_activations("auto")
     la, ga, ma = res[(1, 2, 3, 4)]
     lb, gb, mb = res[(1, 2)]
-    assert torch.isfinite(la).item() and torch.equal(la, lb), (float(la), float(lb))
-    assert ma < 150 and mb < 240, (ma, mb)     # GB held at the peak: every stage / stages 1-2 recomputed
+    lc, gc_, mc = res[()]
+    assert torch.isfinite(la).item() and torch.equal(la, lb) and torch.equal(la, lc), (float(la), float(lb), float(lc))
+    assert ma < 150 and mb < 240 and mc < 262, (ma, mb, mc)     # GB held at the peak: every stage / stages 1-2 / nothing recomputed
+    # neighbours in the chain all -> stages 1-2 -> nothing recomputed differ in the summation order of some blocks' BatchNorm-
+    # backward sums; the ends differ in all of them and the stem sees the amplified total (conditioning of the
+    # default-initialised bf16 network) — where a1 comes from is pinned bit for bit by test_lean_activations_are_bit_identical_and_smaller
     for n in names:
-        sc = float(ga[n].abs().max()) + 1e-30
-        assert float((ga[n] - gb[n]).abs().max()) <= 0.1 * sc, n
-        assert torch.nn.functional.cosine_similarity(ga[n].flatten().double(), gb[n].flatten().double(), dim=0).item() > 0.99, n
+        for (x_, y_, tol, cmin) in ((ga, gb, 0.1, 0.99), (gb, gc_, 0.1, 0.99), (ga, gc_, 0.25, 0.97)):
+            sc = float(x_[n].abs().max()) + 1e-30
+            assert float((x_[n] - y_[n]).abs().max()) <= tol * sc, (n, tol)
+            assert torch.nn.functional.cosine_similarity(x_[n].flatten().double(), y_[n].flatten().double(), dim=0).item() > cmin, (n, cmin)
