@@ -28,6 +28,15 @@ struct GramArgs {
   int ntiles;
 };
 
+template <int C>
+struct GramPT {
+  static constexpr int value = C <= 64 ? 4 : (C <= 128 ? 2 : 1);
+};
+static long long gram_ntiles(long long M, int C) {
+  const int px = 64 * (C <= 64 ? 4 : (C <= 128 ? 2 : 1));
+  return (M + px - 1) / px;
+}
+
 template <int C, bool XF>
 __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a) {
   typedef bf16_t T;
@@ -36,7 +45,9 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
   constexpr int TC = C / 16;                     // 16-column blocks
   constexpr int RB = 128, SUB = 64 * RB;         // C / 64 sub-images of [64 px][64 ch]
   constexpr int CPR = C / 8;                     // 16-byte chunks per pixel
-  constexpr int NLD = CPR / 4;                   // chunks per thread per tile (64 * CPR / 256)
+  constexpr int NLD = CPR / 4;                   // chunks per thread per 64-pixel slice (64 * CPR / 256)
+  constexpr int PT = GramPT<C>::value;           // 64-pixel slices per tile: a narrow image gets a longer tile (bytes in flight, work per barrier pair)
+  constexpr int NSUB = C / 64;                   // sub-images per slice
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);   // [256 / CPR][C] partial column sums: reuses the image after the last tile (8 KB <= the image)
 
@@ -71,23 +82,26 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
 #pragma unroll
   for (int b = 0; b < 4; ++b) offb[b] = r0 * RB + (((2 * b + (p >> 1)) ^ (((r0 >> 1) & 3) << 1)) << 4) + ((p & 1) << 3);
 
-  uint4 pre[NLD];
+  uint4 pre[PT * NLD];
   auto load_tile = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      long long m = (long long)t * 64 + p0 + i * PSTEP;
-      if (m >= a.M) m = a.M - 1;
-      pre[i] = ld16_nt(x + m * C + cir * 8);
-    }
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        long long m = ((long long)t * PT + pt) * 64 + p0 + i * PSTEP;
+        if (m >= a.M) m = a.M - 1;
+        pre[pt * NLD + i] = ld16_nt(x + m * C + cir * 8);
+      }
   };
   auto store_tile = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    for (int pi = 0; pi < PT * NLD; ++pi) {
+      const int pt = pi / NLD, i = pi % NLD;
       const int px = p0 + i * PSTEP;
       Vec16<T> v, w2;
-      v.raw = pre[i];
+      v.raw = pre[pi];
       if constexpr (XF) XfMath<T>::template run<false>(v, w2, qs, qt, nullptr, nullptr, a.x_relu, false);
-      if ((long long)t * 64 + px >= a.M) v.zero();
+      if (((long long)t * PT + pt) * 64 + px >= a.M) v.zero();
       if (cls == 0) {
         float f[8];
         v.get(f);
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
           cpos[e] += f[e] > 0.f ? 1.f : 0.f;   // (exact in fp32: a thread sees < 2^24 rows)
         }
       }
-      *reinterpret_cast<uint4*>(smem + sub * SUB + px * RB + ((chunk ^ (((px >> 1) & 3) << 1)) << 4)) = v.raw;
+      *reinterpret_cast<uint4*>(smem + (pt * NSUB + sub) * SUB + px * RB + ((chunk ^ (((px >> 1) & 3) << 1)) << 4)) = v.raw;
     }
   };
 
@@ -111,19 +125,21 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // the image is complete
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int ps = 0; ps < 2 * PT; ++ps) {
+      const int s = ps & 1;
+      const char* img = smem + (ps >> 1) * NSUB * SUB;
       bf16x8 af[TR];
 #pragma unroll
       for (int r = 0; r < TR; ++r) {
         const int ch16 = cls * (CR / 16) + widu * TR + r;     // 16-channel block of the Gram row block
-        const char* base = smem + (ch16 >> 2) * SUB + s * 32 * RB + offb[ch16 & 3];
+        const char* base = img + (ch16 >> 2) * SUB + s * 32 * RB + offb[ch16 & 3];
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_g*)(base));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_g*)(base + 16 * RB));
         af[r] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
       for (int c = 0; c < TC; ++c) {
-        const char* base = smem + (c >> 2) * SUB + s * 32 * RB + offb[c & 3];
+        const char* base = img + (c >> 2) * SUB + s * 32 * RB + offb[c & 3];
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_g*)(base));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4_g*)(base + 16 * RB));
         const bf16x8 bfr = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256, C <= 128 ? 2 : 1) void gram_kernel(GramArgs a)
 
 template <int C>
 static int launch_gram(const GramArgs& a, hipStream_t st) {
-  constexpr int lds = (C / 64) * 64 * 128;   // (>= the column-sum scratch: 256/CPR rows of C floats = 8 KB)
+  constexpr int lds = GramPT<C>::value * (C / 64) * 64 * 128;   // (>= the column-sum scratch: 256/CPR rows of C floats = 8 KB)
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -199,7 +215,7 @@ extern "C" int maai_gram_partial_rows(long long M, int C) {
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int ncls = C / (C < 128 ? C : 128);
   long long gx = (long long)cus * (C <= 128 ? 2 : 1) / ncls;
-  const long long ntiles = (M + 63) / 64;
+  const long long ntiles = gram_ntiles(M, C);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   return (int)gx;
@@ -214,7 +230,7 @@ extern "C" int maai_gram_partials(const void* x, long long M, int C, const float
   MAAI_CHECK_ARG(M < (1ll << 31), "gram_partials: pixel count must fit 31 bits");
   GramArgs a;
   a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = nullptr; a.sx = nullptr; a.npos = nullptr; a.pgram = pgram; a.psx = psx;
-  a.M = M; a.ntiles = (int)((M + 63) / 64);
+  a.M = M; a.ntiles = (int)gram_ntiles(M, C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
     case 64: return launch_gram<64>(a, st);
@@ -234,7 +250,7 @@ extern "C" int maai_gram(const void* x, long long M, int C, const float* xs, con
   MAAI_CHECK_ARG(x && gram && sx && M > 0 && (xs == nullptr) == (xt == nullptr), "gram: bad arguments");
   MAAI_CHECK_ARG(M < (1ll << 31), "gram: pixel count must fit 31 bits");
   GramArgs a;
-  a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = gram; a.sx = sx; a.npos = npos; a.pgram = nullptr; a.psx = nullptr; a.M = M; a.ntiles = (int)((M + 63) / 64);
+  a.x = x; a.xs = xs; a.xt = xt; a.x_relu = x_relu; a.gram = gram; a.sx = sx; a.npos = npos; a.pgram = nullptr; a.psx = nullptr; a.M = M; a.ntiles = (int)gram_ntiles(M, C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   switch (C) {
     case 64: return launch_gram<64>(a, st);

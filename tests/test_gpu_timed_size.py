@@ -403,11 +403,16 @@ def test_recompute_step_at_512_images_per_gpu():
     lc, gc_, mc = res[()]
     assert torch.isfinite(la).item() and torch.equal(la, lb) and torch.equal(la, lc), (float(la), float(lb), float(lc))
     assert ma < 150 and mb < 240 and mc < 262, (ma, mb, mc)     # GB held at the peak: every stage / stages 1-2 / nothing recomputed
-    # neighbours in the chain all -> stages 1-2 -> nothing recomputed differ in the summation order of some blocks' BatchNorm-
-    # backward sums; the ends differ in all of them and the stem sees the amplified total (conditioning of the
-    # default-initialised bf16 network) — where a1 comes from is pinned bit for bit by test_lean_activations_are_bit_identical_and_smaller
+    # a recomputed block runs the UNFOLDED BatchNorm backward (its conv3 output exists again), a stored one the folded one: two
+    # valid roundings of the same gradient that differ by ~5e-3 per unit (test_gpu_fold.py pins both against fp64), and the
+    # default-initialised bf16 network amplifies that on the way down — 10 % at the stem between neighbours of the
+    # chain all -> stages 1-2 -> nothing recomputed was the bound before this configuration existed, 13-17 % is what its ends
+    # and the pair that differs in stages 1-2 show.  Where a1 comes from is pinned bit for bit by
+    # test_lean_activations_are_bit_identical_and_smaller; the head and stage 4 must agree closely in every pair.
     for n in names:
-        for (x_, y_, tol, cmin) in ((ga, gb, 0.1, 0.99), (gb, gc_, 0.1, 0.99), (ga, gc_, 0.25, 0.97)):
+        deep = n.startswith(("f.layer4", "g."))
+        for (x_, y_) in ((ga, gb), (gb, gc_), (ga, gc_)):
+            tol, cmin = (0.05, 0.995) if deep else (0.25, 0.97)
             sc = float(x_[n].abs().max()) + 1e-30
             assert float((x_[n] - y_[n]).abs().max()) <= tol * sc, (n, tol)
             assert torch.nn.functional.cosine_similarity(x_[n].flatten().double(), y_[n].flatten().double(), dim=0).item() > cmin, (n, cmin)
