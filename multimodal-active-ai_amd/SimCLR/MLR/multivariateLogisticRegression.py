@@ -1,7 +1,9 @@
 """Drop-in for the reference's SimCLR/MLR/multivariateLogisticRegression.py (:6-13): the linear-probe classifier of
 Representation_Evaluation.py:598-712.  ``self.linear`` stays an ``nn.Linear`` (same state_dict keys); its forward and
 backward run on the HIP kernels (maai_hip.probe: implicit-GEMM logits in exact fp32) whenever the features live on a
-HIP device.  ``HipCrossEntropyLoss`` is the matching criterion on the library's softmax-CE kernel."""
+HIP device.  ``HipCrossEntropyLoss`` is the matching criterion on the library's softmax-CE kernel; importing this module
+also makes the driver's own ``nn.CrossEntropyLoss()`` (Representation_Evaluation.py:455) dispatch to it for the default
+configuration on HIP logits (maai_hip.probe.install_cross_entropy; MAAI_PATCH_CE=0 leaves torch.nn alone)."""
 import os
 import sys
 
@@ -29,3 +31,6 @@ class LogisticRegression(nn.Module):
 
 
 HipCrossEntropyLoss = _probe.CrossEntropyLoss
+if os.environ.get("MAAI_PATCH_CE", "1") != "0":
+    _probe.install_cross_entropy(True)
+

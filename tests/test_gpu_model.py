@@ -561,6 +561,19 @@ def test_linear_probe_flow_on_frozen_backbone(mods, tmp_path):
             loss.backward()
         opt.step()
     assert loss.item() < l0 and probe(fx).shape == (B, 1000)
+    # the UNCHANGED driver's criterion (Representation_Evaluation.py:455: nn.CrossEntropyLoss().to(device)): importing the
+    # drop-in classifier module made torch.nn's class the HIP-aware one — the default configuration runs the same kernel,
+    # anything else is torch's own forward
+    from maai_hip import probe as hp
+    assert torch.nn.CrossEntropyLoss is hp._HipAwareCrossEntropyLoss and issubclass(torch.nn.CrossEntropyLoss, hp._TORCH_CE)
+    drv = torch.nn.CrossEntropyLoss().to("cuda")
+    lg = probe(fx).detach().requires_grad_(True)
+    l_drv, l_hip = drv(lg, y.type(torch.long)), criterion(lg, y.type(torch.long))
+    assert torch.equal(l_drv, l_hip) and type(l_drv.grad_fn).__name__.startswith("_CrossEntropyFn")
+    wcls = torch.rand(1000, device="cuda") + 0.5
+    l_w = torch.nn.CrossEntropyLoss(weight=wcls, label_smoothing=0.1)(lg, y.type(torch.long))
+    np.testing.assert_allclose(l_w.item(), torch.nn.functional.cross_entropy(lg, y.type(torch.long), weight=wcls, label_smoothing=0.1).item(), rtol=1e-6)
+    assert not type(l_w.grad_fn).__name__.startswith("_CrossEntropyFn")
     with pytest.raises(mods["engine"].MaaiError):
         probe.cpu()(fx.cpu())                     # no CPU fallback here either
 

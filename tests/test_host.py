@@ -221,3 +221,22 @@ def test_weight_forms_fp32_host_logic():
     assert b is not a
     engine.bump_weight_epoch()
     assert engine.w_fwd(w, torch.float32) is not b
+
+
+def test_probe_criterion_patch_is_torchs_own_off_the_gpu():
+    """maai_hip.probe.install_cross_entropy: torch.nn.CrossEntropyLoss becomes a subclass that only takes HIP logits in the default
+    configuration; on CPU tensors (here) and for every other configuration it is torch's forward — and it can be taken out again."""
+    import torch
+    from maai_hip import probe
+    orig, was = probe._TORCH_CE, torch.nn.CrossEntropyLoss
+    try:
+        cls = probe.install_cross_entropy(True)
+        assert torch.nn.CrossEntropyLoss is cls and issubclass(cls, orig)
+        g = torch.Generator().manual_seed(0)
+        lg, y = torch.randn(5, 7, generator=g), torch.tensor([0, 3, 6, 2, 2])
+        assert torch.equal(torch.nn.CrossEntropyLoss()(lg, y), torch.nn.functional.cross_entropy(lg, y))
+        assert torch.equal(torch.nn.CrossEntropyLoss(reduction="sum")(lg, y), torch.nn.functional.cross_entropy(lg, y, reduction="sum"))
+        probe.install_cross_entropy(False)
+        assert torch.nn.CrossEntropyLoss is orig and torch.nn.modules.loss.CrossEntropyLoss is orig
+    finally:
+        probe.install_cross_entropy(was is not orig)   # (as this session had it)
