@@ -879,13 +879,14 @@ extern "C" int maai_conv2d_wgrad_xf(const maai_conv_desc* d, const void* x, cons
   a.nCoB = a.nCiB = a.nTap = 0; a.pix_per_split = 0;
   a.xs = xs; a.xt = xt; a.x_relu = x_relu;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY") && !xs && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 &&
-      a.pad_w == 1 && a.IH == a.OH && a.IW == a.OW) {
+  if (dtype == MAAI_BF16 && !getenv("MAAI_WGRAD_LEGACY") && !xs && a.KH == 3 && a.KW == 3 && (a.stride == 1 || a.stride == 2) && a.pad_h == 1 &&
+      a.pad_w == 1) {
     // the eight-wave wide patch kernel (conv_wgrad3w.hip).  MAAI_WGRAD_WIDE = 0 (off) | 1 (shape rule, default) | 2 (wherever built)
     const char* e = getenv("MAAI_WGRAD_WIDE");
     const int mode = e ? atoi(e) : 1;
     Wgrad3wArgs w;
     w.x = x; w.dy = dy; w.dw = dw; w.N = a.N; w.H = a.OH; w.W = a.OW; w.Cin = a.Cin; w.Cout = a.Cout;
+    w.IH = a.IH; w.IW = a.IW; w.stride = a.stride;
     w.tilesX = w.tilesY = w.nCoB = w.nCiB = 0; w.npatch = w.per_split = 0;
     bool rule = false;
     if (mode != 0 && maai_wgrad3w_supported(w, &rule) && (mode == 2 || (rule && !getenv("MAAI_WGRAD_PATCH") && !getenv("MAAI_WGRAD_TILE") && !getenv("MAAI_WGRAD_PP"))))

@@ -1,4 +1,4 @@
-// conv_wgrad3w.hip: the eight-wave wide patch kernel for 3x3 stride-1 same-size weight gradients (128 x 9 x 64 blocks of dw)
+// conv_wgrad3w.hip: the eight-wave wide patch kernel for 3x3 weight gradients, pad 1, stride 1 or 2 (128 x 9 x 64 blocks of dw)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -6,7 +6,8 @@ struct Wgrad3wArgs {
   const void* x;
   const void* dy;
   float* dw;
-  int N, H, W, Cin, Cout;
+  int N, H, W, Cin, Cout;   // H, W: the output plane
+  int IH, IW, stride;       // the input plane (= H, W at stride 1); 1 or 2
   int tilesX, tilesY;
   int nCoB, nCiB;
   long long npatch, per_split;

@@ -37,17 +37,24 @@ __device__ __forceinline__ void w3dma16(const void* gsrc, char* lds_dst) {
 // KS (layers with 64 output channels, or an odd multiple of 64): the block is 64(co) x 9 x 64(ci); wave (h, c) owns ALL four
 // output-channel tiles, input-channel tile c, all nine taps — of the K-steps {2h, 2h+1} of every patch (the two wave groups
 // split the pixels of a patch and both add their sums at the end).  Same 36 accumulator tiles, same 26 reads per 36 MFMAs.
-template <int PW, bool KS>
+// S = 2 (the stride-2 3x3 layers that open stages 2-4; PW = 16, not KS): a patch is 16 x 4 OUTPUT pixels (two K-steps), its halo
+// the 9 x 33 input pixels they touch (40 slots per row); output pixel px of a patch row reads slot 2*px + kw of halo row
+// 2*py + kh — the same swizzle keeps the four rows of a transposed read on distinct banks ((slot >> 1) & 3 = (q + (kw >> 1)) & 3).
+template <int PW, bool KS, int S>
 __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
-  constexpr int TH = 128 / PW, HWS = PW + 8, RB = 128;   // patch rows, halo slots per row, bytes per pixel row (64 channels)
-  constexpr int YI = 128 * RB;                           // one dY image (16 KB)
-  constexpr int YB = (KS ? 1 : 2) * YI, HB = (TH + 2) * HWS * RB;   // dY bytes (32 KB; KS: 16 KB), halo bytes (30 KB)
+  static_assert(S == 1 || (S == 2 && PW == 16 && !KS), "stride 2: 16-wide patches, 128 output channels per block");
+  constexpr int NPX = S == 1 ? 128 : 64;                 // output pixels per patch
+  constexpr int TH = NPX / PW, RB = 128;                 // patch rows, bytes per pixel row (64 channels)
+  constexpr int HR = S * (TH - 1) + 3, VC = S * (PW - 1) + 3;   // halo rows, valid halo columns
+  constexpr int HWS = S == 1 ? PW + 8 : 40;              // halo slots per row
+  constexpr int YI = NPX * RB, IPI = YI / 1024;          // one dY image (16 KB; S = 2: 8 KB), DMA instructions per image
+  constexpr int YB = (KS ? 1 : 2) * YI, HB = HR * HWS * RB;   // dY bytes (32 KB; KS: 16 KB), halo bytes (30 KB; S = 2: 45 KB)
   constexpr int NIY = YB / 1024, NIH = HB / 1024;        // wave-wide DMA instructions: 32 (KS: 16) + 30
-  constexpr int PB = YB + HB;                            // one patch buffer (62 KB; KS: 46 KB)
+  constexpr int PB = YB + HB;                            // one patch buffer (62 KB; KS: 46 KB; S = 2: 61 KB)
   constexpr int NDI = (NIY + NIH + 7) / 8;
-  constexpr int ROWSTEP = PW == 16 ? 2 : 1;              // halo rows per K-step
-  constexpr int HI_OFF = PW == 16 ? HWS * RB : 16 * RB;  // where the second 16 pixels of a K-step sit relative to the first
-  static_assert(HB % 1024 == 0 && HWS % 8 == 0, "halo geometry");
+  constexpr int ROWSTEP = S == 2 ? 4 : (PW == 16 ? 2 : 1);          // halo rows per K-step
+  constexpr int HI_OFF = S == 2 ? 2 * HWS * RB : (PW == 16 ? HWS * RB : 16 * RB);   // where the second 16 pixels of a K-step sit relative to the first
+  static_assert(HB % 1024 == 0 && HWS % 8 == 0 && VC <= HWS, "halo geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int widu = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const int hr = r0 + k;   // slot x-index of this lane's pixel at shift kw = k (slot 0 is column -1)
+    const int hr = S * r0 + k;   // slot x-index of this lane's pixel at shift kw = k (slot 0 is input column S*ox0 - 1)
     offB[k] = YB + hr * RB + ((p & 1) << 3) + ((((p >> 1) ^ (((hr >> 1) & 3) << 1)) << 4) ^ (ct << 5));
   }
   const int tpi = a.tilesX * a.tilesY;
@@ -98,13 +105,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
     const int qi = widu + 8 * i;
     rel[i] = 0;
     if (qi < NIY) {
-      const int row = (qi & 15) * 8 + drow;   // pixel of the patch; image qi >> 4
-      rel[i] = ((row / PW) * a.W + (row % PW)) * a.Cout + co0 + (qi >> 4) * 64 + (dch ^ (((row >> 1) & 3) << 1)) * 8;
+      const int row = (qi % IPI) * 8 + drow;   // pixel of the patch; image qi / IPI
+      rel[i] = ((row / PW) * a.W + (row % PW)) * a.Cout + co0 + (qi / IPI) * 64 + (dch ^ (((row >> 1) & 3) << 1)) * 8;
     } else if (qi < NIY + NIH) {
       const int hp = (qi - NIY) * 8 + drow;
       const int hy = hp / HWS, hx = hp - hy * HWS;
-      rel[i] = ((hy - 1) * a.W + (hx - 1)) * a.Cin + ci0 + (dch ^ (((hp >> 1) & 3) << 1)) * 8;
-      if (hx >= PW + 2) padmask |= 1u << i;
+      rel[i] = ((hy - 1) * a.IW + (hx - 1)) * a.Cin + ci0 + (dch ^ (((hp >> 1) & 3) << 1)) * 8;
+      if (hx >= VC) padmask |= 1u << i;
     }
   }
 
@@ -113,10 +120,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
     const int rem = (int)(pt - (long long)n * tpi);
     const int tyi = rem / a.tilesX;
     const int oy0 = tyi * TH, ox0 = (rem - tyi * a.tilesX) * PW;
-    if (oy0 >= 1 && ox0 >= 1 && oy0 + TH + 1 <= a.H && ox0 + PW + 1 <= a.W) {
-      const long long pix0 = ((long long)n * a.H + oy0) * a.W + ox0;
-      const bf16_t* by = dy + pix0 * a.Cout;
-      const bf16_t* bx = x + pix0 * a.Cin;
+    if (oy0 >= 1 && ox0 >= 1 && oy0 + TH <= a.H && ox0 + PW <= a.W && S * oy0 - 1 + HR <= a.IH && S * ox0 - 1 + VC <= a.IW) {
+      const bf16_t* by = dy + (((long long)n * a.H + oy0) * a.W + ox0) * a.Cout;
+      const bf16_t* bx = x + (((long long)n * a.IH + S * oy0) * a.IW + S * ox0) * a.Cin;
 #pragma unroll
       for (int i = 0; i < NDI; ++i) {
         const int qi = widu + 8 * i;
@@ -132,18 +138,18 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
       for (int i = 0; i < NDI; ++i) {
         const int qi = widu + 8 * i;   // wave-uniform instruction index
         if (qi < NIY) {
-          const int row = (qi & 15) * 8 + drow;
+          const int row = (qi % IPI) * 8 + drow;
           const int oy = oy0 + row / PW, ox = ox0 + row % PW;
           const int sc = dch ^ (((row >> 1) & 3) << 1);
-          const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + (qi >> 4) * 64 + sc * 8 : zsrc;
+          const bf16_t* src = (oy < a.H && ox < a.W) ? dy + (((long long)n * a.H + oy) * a.W + ox) * a.Cout + co0 + (qi / IPI) * 64 + sc * 8 : zsrc;
           w3dma16(src, buf + qi * 1024);
         } else if (qi < NIY + NIH) {
           const int hp = (qi - NIY) * 8 + drow;
           const int hy = hp / HWS, hx = hp - hy * HWS;
-          const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+          const int iy = S * oy0 + hy - 1, ix = S * ox0 + hx - 1;
           const int sc = dch ^ (((hp >> 1) & 3) << 1);
-          const bool ok = hx < PW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-          const bf16_t* src = ok ? x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + ci0 + sc * 8 : zsrc;
+          const bool ok = hx < VC && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+          const bf16_t* src = ok ? x + (((long long)n * a.IH + iy) * a.IW + ix) * a.Cin + ci0 + sc * 8 : zsrc;
           w3dma16(src, buf + qi * 1024);
         }
       }
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
       }
     };
     bf16x8 af[4], bcur[3], bnxt[3];
-    constexpr int NS = KS ? 2 : 4;
+    constexpr int NS = KS ? 2 : NPX / 32;
     const int s0 = KS ? 2 * half : 0;
     load_a(s0, af);
     load_b(s0, 0, bcur);
@@ -232,20 +238,26 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_wide_kernel(Wgrad3wArgs a) {
 }
 
 static void w3_geometry(const Wgrad3wArgs& a, int pw, int* tx, int* ty, double* cover) {
-  const int th = 128 / pw;
+  const int th = (a.stride == 2 ? 64 : 128) / pw;
   *tx = (a.W + pw - 1) / pw;
   *ty = (a.H + th - 1) / th;
   *cover = (double)a.H * a.W / ((double)*tx * pw * *ty * th);
 }
 
-// MAAI_WGRAD_WIDE = 0 | 1 (shape rule, default) | 2 (every shape it is built for), read per call
+// MAAI_WGRAD_WIDE = 0 | 1 (shape rule, default) | 2 (every shape it is built for), read per call.
+// a.H, a.W: the OUTPUT plane (= the input plane at stride 1); a.IH, a.IW: the input plane.
 bool maai_wgrad3w_supported(const Wgrad3wArgs& a, bool* by_rule) {
   if (!(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.H >= 3 && a.W >= 3)) return false;
+  if (a.stride == 2) {
+    if (!(a.Cout % 128 == 0 && a.H == (a.IH - 1) / 2 + 1 && a.W == (a.IW - 1) / 2 + 1)) return false;
+  } else if (!(a.stride == 1 && a.IH == a.H && a.IW == a.W)) {
+    return false;
+  }
   int tx, ty;
   double c16, c32;
   w3_geometry(a, 16, &tx, &ty, &c16);
   w3_geometry(a, 32, &tx, &ty, &c32);
-  const double cover = c16 > c32 ? c16 : c32;
+  const double cover = a.stride == 2 ? c16 : (c16 > c32 ? c16 : c32);
   *by_rule = cover >= 0.85 && (long long)a.N * a.H * a.W >= 65536;
   return true;
 }
@@ -258,6 +270,7 @@ int maai_wgrad3w_launch(Wgrad3wArgs a, hipStream_t st, int target) {
   int pw = c32 > c16 + 1e-9 ? 32 : 16;
   const char* e = getenv("MAAI_WGRAD_WIDE_PW");
   if (e && (atoi(e) == 16 || atoi(e) == 32)) pw = atoi(e);
+  if (a.stride == 2) pw = 16;
   a.tilesX = pw == 16 ? tx16 : tx32;
   a.tilesY = pw == 16 ? ty16 : ty32;
   const bool ks = a.Cout % 128 != 0;
@@ -271,19 +284,21 @@ int maai_wgrad3w_launch(Wgrad3wArgs a, hipStream_t st, int target) {
   if (split < 1) split = 1;
   a.per_split = (a.npatch + split - 1) / split;
   split = (a.npatch + a.per_split - 1) / a.per_split;
-  const int lds = 2 * ((ks ? 1 : 2) * 128 * 128 + 240 * 128);   // two patch buffers of 62 KB (KS: 46 KB)
-  static int attr[4][64] = {{0}};
+  // two patch buffers: dY (two images; KS: one) + halo — 62 KB (KS: 46 KB; stride 2: 16 + 45 = 61 KB)
+  const int lds = a.stride == 2 ? 2 * (2 * 64 * 128 + 9 * 40 * 128) : 2 * ((ks ? 1 : 2) * 128 * 128 + 240 * 128);
+  static int attr[5][64] = {{0}};
   const dim3 grid((unsigned)(tiles * split));
-#define MAAI_W3_LAUNCH(PW_, KS_, slot)                                                                     \
-  do {                                                                                                     \
-    maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_wide_kernel<PW_, KS_>), lds, attr[slot]);       \
-    MAAI_NOTE_KERNEL(wgrad3x3_wide_kernel<PW_, KS_>);                                                      \
-    hipLaunchKernelGGL((wgrad3x3_wide_kernel<PW_, KS_>), grid, dim3(512), lds, st, a);                     \
+#define MAAI_W3_LAUNCH(PW_, KS_, S_, slot)                                                                      \
+  do {                                                                                                          \
+    maai_ensure_lds(reinterpret_cast<const void*>(&wgrad3x3_wide_kernel<PW_, KS_, S_>), lds, attr[slot]);        \
+    MAAI_NOTE_KERNEL(wgrad3x3_wide_kernel<PW_, KS_, S_>);                                                       \
+    hipLaunchKernelGGL((wgrad3x3_wide_kernel<PW_, KS_, S_>), grid, dim3(512), lds, st, a);                      \
   } while (0)
-  if (pw == 16 && !ks) MAAI_W3_LAUNCH(16, false, 0);
-  else if (pw == 16) MAAI_W3_LAUNCH(16, true, 1);
-  else if (!ks) MAAI_W3_LAUNCH(32, false, 2);
-  else MAAI_W3_LAUNCH(32, true, 3);
+  if (a.stride == 2) MAAI_W3_LAUNCH(16, false, 2, 4);
+  else if (pw == 16 && !ks) MAAI_W3_LAUNCH(16, false, 1, 0);
+  else if (pw == 16) MAAI_W3_LAUNCH(16, true, 1, 1);
+  else if (!ks) MAAI_W3_LAUNCH(32, false, 1, 2);
+  else MAAI_W3_LAUNCH(32, true, 1, 3);
 #undef MAAI_W3_LAUNCH
   MAAI_CHECK_LAUNCH();
   return MAAI_OK;

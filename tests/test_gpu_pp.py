@@ -220,6 +220,11 @@ WIDE_CASES = [
     (2, 30, 33, 64, 64, 32),
     (2, 19, 37, 128, 192, 32),
     (1, 5, 3, 64, 64, 16),
+    # stride 2 (the 3x3 layers that open stages 2-4): 16 x 4 output patches, 9 x 33 input halos — PW < 0 marks them
+    (3, 32, 32, 128, 128, -16),
+    (2, 57, 57, 256, 256, -16),     # odd input extent (OH = 29): ragged patches on both axes
+    (2, 28, 28, 64, 128, -16),
+    (1, 7, 5, 64, 128, -16),        # a plane smaller than one patch
 ]
 
 
@@ -230,19 +235,22 @@ def test_wide_patch_weight_gradient_matches_patch_kernel_and_fp64(K, case):
     (resnet.py:20-23): same products, fp32 sums in a different order; and it is the kernel that ran."""
     from maai_hip._lib import lib
     n, h, w_, cin, cout, pw = case
+    stride = 2 if pw < 0 else 1
+    pw = abs(pw)
     g = torch.Generator().manual_seed(sum(case) + 3)
     x = torch.randn(n, h, w_, cin, generator=g).cuda().bfloat16()
-    dy = (torch.randn(n, h, w_, cout, generator=g) * 0.05).cuda().bfloat16()
+    oh, ow = (h - 1) // stride + 1, (w_ - 1) // stride + 1
+    dy = (torch.randn(n, oh, ow, cout, generator=g) * 0.05).cuda().bfloat16()
     K.AUTOTUNE[0] = False
     were = lib().maai_kernel_names(1)
     try:
         with env(MAAI_WGRAD_WIDE="0", MAAI_WGRAD_PP="0"):
-            d0 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1)
+            d0 = K.conv2d_wgrad(x, dy, 3, 3, stride, 1, 1)
             assert b"wide" not in lib().maai_last_kernel_name()
         with env(MAAI_WGRAD_WIDE="2", MAAI_WGRAD_WIDE_PW=str(pw)):
-            d1 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1)
-            assert b"wgrad3x3_wide_kernel<%d, %s>" % (pw, b"true" if cout % 128 else b"false") in lib().maai_last_kernel_name()
-            d2 = K.conv2d_wgrad(x, dy, 3, 3, 1, 1, 1, target_blocks=3072)   # a different pixel split
+            d1 = K.conv2d_wgrad(x, dy, 3, 3, stride, 1, 1)
+            assert b"wgrad3x3_wide_kernel<%d, %s, %d>" % (pw, b"true" if cout % 128 else b"false", stride) in lib().maai_last_kernel_name()
+            d2 = K.conv2d_wgrad(x, dy, 3, 3, stride, 1, 1, target_blocks=3072)   # a different pixel split
     finally:
         K.AUTOTUNE[0] = True
         lib().maai_kernel_names(were)
@@ -252,6 +260,6 @@ def test_wide_patch_weight_gradient_matches_patch_kernel_and_fp64(K, case):
     assert float((d1 - d0).abs().max()) <= 2e-5 * scale + 1e-6, float((d1 - d0).abs().max() / scale)
     assert float((d1 - d2).abs().max()) <= 2e-5 * scale + 1e-6      # (fp32 atomics: not bit-reproducible, documented)
     wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wz, None, 1, 1).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wz, None, stride, 1).backward(dy.double().cpu().permute(0, 3, 1, 2))
     ref = wz.grad.permute(0, 2, 3, 1)
     np.testing.assert_allclose(d1.cpu().double().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * float(ref.abs().max()))
