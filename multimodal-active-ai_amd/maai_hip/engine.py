@@ -1314,10 +1314,12 @@ def stem_input(x, conv1, dtype):
 # Block recompute (MAAI_RECOMPUTE=1 / set_recompute): the forward keeps, per residual block, only its input and the
 # per-unit BatchNorm statistics; the backward re-runs the block's forward from them (same kernels, no statistics
 # epilogues, bit-identical tensors) just before differentiating it.  Activation memory drops from ~12 to ~4 C-wide
-# tensors per block — what lets 512 images per GPU (global batch 4096 on 8 GPUs, BASELINE configs[2]) fit in 288 GB —
-# for one extra forward of the differentiated view.
-# Which stages: MAAI_RECOMPUTE_LAYERS (default "1,2").  Layers 1 and 2 hold ~80 % of the activation bytes and cost ~60 % of a
-# forward; keeping layers 3 and 4 stored saves their second forward (512 images / GPU: 129 -> ~225 GB, 643 -> ~690 images/s).
+# tensors per block for one extra forward of the differentiated view.  (Round 4: 512 images per GPU — global batch 4096 on 8
+# GPUs, BASELINE configs[2] — fit the device's 309 GB WITHOUT it once the activations are lean, _LEAN below: 250 GB, 915
+# images/s; recompute is the memory knob beyond that.)
+# Which stages: MAAI_RECOMPUTE_LAYERS (default "1,2"; bench.py --recompute asks for stage 1).  Layers 1 and 2 hold ~80 % of the
+# activation bytes and cost ~60 % of a forward; keeping layers 3 and 4 stored saves their second forward (512 images / GPU,
+# round 4: every stage 129 GB, stages 1-2 201 GB / 806 images/s, stage 1 242 GB / 849 images/s).
 _RECOMPUTE = {"enabled": os.environ.get("MAAI_RECOMPUTE", "0") == "1",
               "layers": frozenset(int(v) for v in os.environ.get("MAAI_RECOMPUTE_LAYERS", "1,2").split(",") if v.strip())}
 
