@@ -149,3 +149,65 @@ def test_contrastive_driver_inner_loop_on_gpu():
     # the four foveal views differ (different crop scales) and a new fixation changes them
     v = [t.float().mean().item() for t in out[0]]
     assert len(set(round(x, 3) for x in v)) > 1
+
+
+@pytest.mark.gpu
+def test_probe_driver_inner_loop_on_gpu():
+    """train_classifier() of the reference's probe driver (Representation_Evaluation.py:598-712): frozen backbone in eval mode,
+    four-scale fixations from the LABELLED foveated processor, features stacked over fixations, the drop-in LogisticRegression
+    and — as that driver writes it — ``criterion = nn.CrossEntropyLoss().to(device)``, which the drop-in classifier module has
+    made the HIP-aware class: nothing in the flow is patched by the test."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    import NVIDIA_DALI_Pipelines as NDP
+    import resnet as rn
+    import SimCLR
+    import Model_Util
+    mlr_dir = os.path.join(SIM, "MLR")
+    if mlr_dir not in sys.path:
+        sys.path.append(mlr_dir)
+    import multivariateLogisticRegression as MLR
+    import torch.nn as nn
+    B, NFIX, NCLS = 16, 2, 10
+    os.environ["MAAI_SYNTHETIC_DATA"] = str(4 * B)
+    pipe1 = NDP.ImagenetReader(batch_size=B, num_threads=2, device_id=0, file_root="/nonexistent/train", shard_id=0, num_shards=1, dali_cpu=False)
+    pipe1.build()
+    os.environ.pop("MAAI_SYNTHETIC_DATA", None)
+    images, labels = NDP.ImageCollector(), NDP.LabelCollector()
+    fixation = NDP.FixationCommand(B)
+    pipe2 = NDP.LabeledFoveatedRetinalProcessor(batch_size=B, num_threads=2, device_id=0, fixation_information=fixation, images=images,
+                                                labels=labels, dali_cpu=False)
+    pipe2.build()
+    f = rn.resnet18().cuda()
+    model = SimCLR.SimCLR_Module(f, Model_Util.Identity(), B, (30, 30), "cuda").cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.eval()
+    classifier = MLR.LogisticRegression(512 * 4 * 4 * NFIX, NCLS).cuda()
+    criterion = nn.CrossEntropyLoss().to("cuda")                     # Representation_Evaluation.py:455, verbatim
+    optimizer = torch.optim.SGD(classifier.parameters(), lr=0.05)
+    classifier.train()
+    losses = []
+    for i in range(3):
+        images.data, labels.data = pipe1.run()                       # (:611-620)
+        inputs = []
+        with torch.no_grad():
+            NDP.fixation_angle = torch.repeat_interleave(torch.Tensor([0]), B).view(-1, 1)
+            for j in range(NFIX):
+                NDP.fixation_pos_x, NDP.fixation_pos_y = torch.rand((B, 1)), torch.rand((B, 1))
+                out = NDP.pytorch_wrapper([pipe2])
+                inputs.append(model(out[0][:4]).view(B, 512 * 4 * 4))
+            inputs = torch.stack(inputs, dim=2).view(B, 512 * 4 * 4 * NFIX)
+        lab = torch.transpose(out[0][4], 0, 1).squeeze(0) % NCLS     # (:656-658; synthetic labels folded into NCLS classes)
+        outputs = classifier(inputs)
+        loss = criterion(outputs, lab.type(torch.long))
+        assert type(loss.grad_fn).__name__.startswith("_CrossEntropyFn")   # the library's softmax-CE kernel, not torch's
+        ref = torch.nn.functional.cross_entropy(outputs.detach().float(), lab.type(torch.long))
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-5)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        losses.append(loss.item())
+        prec1 = Model_Util.top_k_accuracy(outputs, lab, 1)
+        assert 0.0 <= float(prec1) <= 1.0
+    assert all(np.isfinite(losses)) and classifier.linear.weight.grad is not None
