@@ -36,10 +36,14 @@ __device__ __forceinline__ void dfold_wait_vm() {
 
 // RESIDENT: all ten weight stages (40 KB) are requested at once, right behind the operand loads, and the K loop runs behind ONE
 // wait + barrier instead of ten (the ring version waits for an L2 round trip and a barrier per 8 MFMAs of a wave).
-// (two workgroups per CU: at three the 170-register budget spilled 24-42 registers per lane to scratch — 25-45 % extra memory
-//  traffic on a kernel that has nothing but memory traffic; two keep 196 KB of operand loads in flight per CU)
+// Three workgroups per CU (12 waves, 168 registers each).  A workgroup's life is a latency chain — operand loads, weights,
+// K loop, epilogue, ~12 us of which ~2 us depend on its bytes (halving the rows per workgroup changed it from 12.4 to 11.5 us) —
+// so what a CU streams is (workgroups resident) x (bytes each) / (that chain).  At three the first build spilled 24-42
+// registers per lane (25-45 % extra traffic on a kernel that has nothing but traffic); the 40 registers in question were the
+// epilogue's per-channel coefficients, held through the K loop: they are read from the LDS coefficient table in the epilogue
+// now.  2.45 -> 2.11 ms per launch (4.0 -> 4.7 TB/s), accumulate form 2.64 -> 2.51.
 template <bool ACC, bool RESIDENT>
-__global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
+__global__ __launch_bounds__(256, 3) void conv_dfold_kernel(DfoldArgs a) {
   typedef bf16_t T;
   constexpr int TM = 2, BM = 128, KC1 = 256, KC2 = 64, K = KC1 + KC2, KT1 = KC1 / 32, KT2 = KC2 / 32, KT = KT1 + KT2;
   constexpr int BN = 64, TN = 4, STAGE = BN * 64, DIST = RESIDENT ? 10 : 3, NSLOT = RESIDENT ? 10 : DIST + 2, RING = NSLOT * STAGE;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
   typedef Mma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem + RING + 4 * CW);   // [4 waves][2][64]
-  float* xcoef = red + 8 * BN;                                     // s2 | t2
+  float* xcoef = red + 8 * BN;                                     // s2 | t2 | mean2 | dg | cn (the epilogue reads its coefficients from here)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int widu = __builtin_amdgcn_readfirstlane(wid);
@@ -59,7 +63,10 @@ __global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
   const bool full = (long long)(mb + 1) * BM <= a.M;
   const int li = lane & 15, gl = lane >> 4;
 
-  for (int i = tid; i < 2 * KC2; i += 256) xcoef[i] = i < KC2 ? a.s2[i] : a.t2[i - KC2];
+  for (int i = tid; i < 5 * KC2; i += 256) {
+    const int which = i / KC2, c = i - which * KC2;
+    xcoef[i] = which == 0 ? a.s2[c] : which == 1 ? a.t2[c] : which == 2 ? a.mean2[c] : which == 3 ? (a.dg ? a.dg[c] : 0.f) : a.cn[c];
+  }
 
   // ---- the A operand: rows mb*128 + wid*32 + i*16 + li; chunks 0..7 from g, 8..9 from y2 (normalised below) ----
   const long long arow0 = (long long)mb * BM + widu * (16 * TM);
@@ -87,18 +94,6 @@ __global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
       yv[i * NIT + it] = *reinterpret_cast<const uint4*>(y2p + m * KC2 + ec * 8);
       if constexpr (ACC) pv[i * NIT + it] = *reinterpret_cast<const uint4*>(dx + m * BN + ec * 8);
     }
-  float cnc[4], m2[8], sc2[8], sh2[8], dgr[8], s1[8], s2[8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cnc[j] = a.cn[j * 16 + (lane & 15)];   // C layout: this lane's column of accumulator tile j
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    m2[e] = a.mean2[ec * 8 + e];
-    dgr[e] = a.dg ? a.dg[ec * 8 + e] : 0.f;
-    sc2[e] = a.s2[ec * 8 + e];
-    sh2[e] = a.t2[ec * 8 + e];
-    s1[e] = 0.f;
-    s2[e] = 0.f;
-  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();   // the coefficient table is in LDS (no LDS-DMA in flight yet)
 #pragma unroll
@@ -179,6 +174,20 @@ __global__ __launch_bounds__(256, 2) void conv_dfold_kernel(DfoldArgs a) {
   }
 
   // ---- epilogue: wave-private C area -> rows of 8 channels per lane; + cn (+ previous), mask, sums, store ----
+  // (the per-channel coefficients come from the LDS table only now: held in registers through the K loop they cost the 40
+  //  registers that separate two workgroups per CU from three)
+  float cnc[4], m2[8], sc2[8], sh2[8], dgr[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cnc[j] = xcoef[4 * KC2 + j * 16 + (lane & 15)];   // C layout: this lane's column of accumulator tile j
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc2[e] = xcoef[ec * 8 + e];
+    sh2[e] = xcoef[KC2 + ec * 8 + e];
+    m2[e] = xcoef[2 * KC2 + ec * 8 + e];
+    dgr[e] = xcoef[3 * KC2 + ec * 8 + e];
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -267,7 +276,7 @@ extern "C" int maai_conv_dfold(const void* g, const void* y2, const void* w, con
   a.g = g; a.y2 = y2; a.w = w; a.cn = cn; a.dg = dg; a.mean2 = mean2; a.s2 = s2; a.t2 = t2; a.dx = dx; a.slab = slab; a.M = M;
   a.nMB = (int)((M + 127) / 128);
   static const bool resident = !(getenv("MAAI_DFOLD_RESIDENT") && atoi(getenv("MAAI_DFOLD_RESIDENT")) == 0);   // A/B knob
-  const int lds = (resident ? 10 : 5) * 64 * 64 + 4 * 16 * 72 * 2 + 8 * 64 * 4 + 2 * 64 * 4;
+  const int lds = (resident ? 10 : 5) * 64 * 64 + 4 * 16 * 72 * 2 + 8 * 64 * 4 + 5 * 64 * 4;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   static int attr[4][64] = {{0}};
 #define MAAI_DFOLD_LAUNCH(ACCV, RESV, SLOT)                                                                          \
